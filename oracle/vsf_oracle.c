@@ -1,0 +1,823 @@
+/*
+ * vsf_oracle.c -- CPU ORACLE (test infrastructure only; see vsf_oracle.h for the "parity
+ * unpinned" statement).  Plain C99, no dependencies.  Build: see oracle/Makefile
+ * (-O2 -ffp-contract=off, no fast-math, so every float expression below is evaluated exactly
+ * as written).
+ *
+ * Citations: "ref:" = file:line under /root/reference (the wrapper logic this follows);
+ * "cv:" = the OpenCV 3.4 function whose published algorithm is restated (SURVEY.md Appendix A;
+ * OpenCV sources are not available offline).
+ */
+#include "vsf_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* helpers                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+
+/* cv: borderInterpolate(p, len, BORDER_REFLECT_101) */
+static inline int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) {
+    if (p < 0)
+      p = -p;
+    else
+      p = 2 * len - 2 - p;
+  }
+  return p;
+}
+
+/* cv: cvRound(float) == round-half-to-even under the default rounding mode */
+static inline int cv_round_f(float v) { return (int)lrintf(v); }
+static inline int cv_round_d(double v) { return (int)lrint(v); }
+static inline int cv_floor_f(float v) { return (int)floorf(v); }
+
+#define CV_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+/* ------------------------------------------------------------------------------------------ */
+/* cv: pyrDown (8-bit, 5x5 [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101) -- SURVEY A.2             */
+/* ------------------------------------------------------------------------------------------ */
+void orc_pyr_down_u8(const uint8_t* src, int w, int h, int stride, uint8_t* dst) {
+  const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+  int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 5);
+  for (int y = 0; y < dh; y++) {
+    for (int k = 0; k < 5; k++) {
+      const int sy = reflect101(2 * y - 2 + k, h);
+      const uint8_t* s = src + (size_t)sy * stride;
+      int* r = rows + (size_t)k * dw;
+      for (int x = 0; x < dw; x++) {
+        const int x0 = reflect101(2 * x - 2, w), x1 = reflect101(2 * x - 1, w);
+        const int x2 = reflect101(2 * x, w), x3 = reflect101(2 * x + 1, w);
+        const int x4 = reflect101(2 * x + 2, w);
+        r[x] = s[x0] + 4 * s[x1] + 6 * s[x2] + 4 * s[x3] + s[x4];
+      }
+    }
+    for (int x = 0; x < dw; x++) {
+      const int v = rows[x] + 4 * rows[dw + x] + 6 * rows[2 * dw + x] + 4 * rows[3 * dw + x] +
+                    rows[4 * dw + x];
+      dst[(size_t)y * dw + x] = (uint8_t)((v + 128) >> 8);
+    }
+  }
+  free(rows);
+}
+
+/* cv: buildOpticalFlowPyramid(img, pyr, winSize, maxLevel, withDerivatives=false).
+ * Level 0 is the image; level l = pyrDown(level l-1); after building level l the next size is
+ * computed and the build stops (returning l) when it is <= the window in either dimension.
+ * The per-level REFLECT_101 border OpenCV stores is replaced by index reflection at the readers
+ * (identical values). */
+int orc_build_pyramid(const uint8_t* img, int w, int h, int stride, int win, int max_level,
+                      orc_pyramid* out) {
+  memset(out, 0, sizeof(*out));
+  if (max_level >= ORC_MAX_LEVELS) max_level = ORC_MAX_LEVELS - 1;
+  int cw = w, ch = h;
+  for (int level = 0; level <= max_level; level++) {
+    orc_level* L = &out->lv[level];
+    L->w = cw;
+    L->h = ch;
+    L->data = (uint8_t*)malloc((size_t)cw * ch);
+    if (level == 0) {
+      for (int y = 0; y < ch; y++) memcpy(L->data + (size_t)y * cw, img + (size_t)y * stride, cw);
+    } else {
+      const orc_level* P = &out->lv[level - 1];
+      orc_pyr_down_u8(P->data, P->w, P->h, P->w, L->data);
+    }
+    out->max_level = level;
+    cw = (cw + 1) / 2;
+    ch = (ch + 1) / 2;
+    if (cw <= win || ch <= win) break;
+  }
+  return out->max_level;
+}
+
+void orc_free_pyramid(orc_pyramid* p) {
+  for (int i = 0; i < ORC_MAX_LEVELS; i++) {
+    free(p->lv[i].data);
+    p->lv[i].data = NULL;
+  }
+}
+
+/* cv: calcSharrDeriv (video/lkpyramid.cpp) -- SURVEY A.3.  dxy is interleaved (Ix, Iy) int16. */
+void orc_scharr_s16(const uint8_t* src, int w, int h, int stride, int16_t* dxy) {
+  int* t0 = (int*)malloc(sizeof(int) * (size_t)(w + 2) * 2);
+  int* t1 = t0 + (w + 2);
+  for (int y = 0; y < h; y++) {
+    const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : (h > 1 ? 1 : 0)) * stride;
+    const uint8_t* r1 = src + (size_t)y * stride;
+    const uint8_t* r2 = src + (size_t)(y < h - 1 ? y + 1 : (h > 1 ? h - 2 : 0)) * stride;
+    for (int x = 0; x < w; x++) {
+      t0[x + 1] = (r0[x] + r2[x]) * 3 + r1[x] * 10;
+      t1[x + 1] = r2[x] - r0[x];
+    }
+    const int xl = (w > 1 ? 1 : 0), xr = (w > 1 ? w - 2 : 0);
+    t0[0] = t0[xl + 1];
+    t0[w + 1] = t0[xr + 1];
+    t1[0] = t1[xl + 1];
+    t1[w + 1] = t1[xr + 1];
+    int16_t* d = dxy + (size_t)y * w * 2;
+    for (int x = 0; x < w; x++) {
+      d[2 * x] = (int16_t)(t0[x + 2] - t0[x]);
+      d[2 * x + 1] = (int16_t)((t1[x + 2] + t1[x]) * 3 + t1[x + 1] * 10);
+    }
+  }
+  free(t0);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cv: calcOpticalFlowPyrLK / LKTrackerInvoker scalar path -- SURVEY A.4                       */
+/* ------------------------------------------------------------------------------------------ */
+static inline int lvl_I(const orc_level* L, int x, int y) {
+  return L->data[(size_t)reflect101(y, L->h) * L->w + reflect101(x, L->w)];
+}
+/* derivative image is padded with zeros (BORDER_CONSTANT) */
+static inline int lvl_D(const orc_level* L, const int16_t* d, int x, int y, int c) {
+  if (x < 0 || y < 0 || x >= L->w || y >= L->h) return 0;
+  return d[((size_t)y * L->w + x) * 2 + c];
+}
+
+static void lk_level(const orc_level* I, const int16_t* dI, const orc_level* J,
+                     const float* prev_pts, float* next_pts, uint8_t* status, float* err, int n,
+                     int win, int level, int max_level, int max_count, double epsilon,
+                     double min_eig_thr, int acc_mode, int16_t* Iw, int16_t* dIw) {
+  const float half = (win - 1) * 0.5f;
+  const float FLT_SCALE = 1.f / (1 << 20);
+  const int W_BITS = 14;
+  for (int i = 0; i < n; i++) {
+    float px = prev_pts[2 * i] * (float)(1. / (1 << level));
+    float py = prev_pts[2 * i + 1] * (float)(1. / (1 << level));
+    float nx, ny;
+    if (level == max_level) {
+      nx = px;
+      ny = py;
+    } else {
+      nx = next_pts[2 * i] * 2.f;
+      ny = next_pts[2 * i + 1] * 2.f;
+    }
+    next_pts[2 * i] = nx;
+    next_pts[2 * i + 1] = ny;
+
+    px -= half;
+    py -= half;
+    int ipx = cv_floor_f(px), ipy = cv_floor_f(py);
+    if (ipx < -win || ipx >= I->w || ipy < -win || ipy >= I->h) {
+      if (level == 0) {
+        status[i] = 0;
+        if (err) err[i] = 0;
+      }
+      continue;
+    }
+    float a = px - ipx, b = py - ipy;
+    int iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+    int iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+    int iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+    int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+
+    float fA11 = 0, fA12 = 0, fA22 = 0;
+    int64_t eA11 = 0, eA12 = 0, eA22 = 0;
+    for (int y = 0; y < win; y++) {
+      for (int x = 0; x < win; x++) {
+        const int X = ipx + x, Y = ipy + y;
+        int ival = CV_DESCALE(lvl_I(I, X, Y) * iw00 + lvl_I(I, X + 1, Y) * iw01 +
+                                  lvl_I(I, X, Y + 1) * iw10 + lvl_I(I, X + 1, Y + 1) * iw11,
+                              W_BITS - 5);
+        int ixval = CV_DESCALE(lvl_D(I, dI, X, Y, 0) * iw00 + lvl_D(I, dI, X + 1, Y, 0) * iw01 +
+                                   lvl_D(I, dI, X, Y + 1, 0) * iw10 +
+                                   lvl_D(I, dI, X + 1, Y + 1, 0) * iw11,
+                               W_BITS);
+        int iyval = CV_DESCALE(lvl_D(I, dI, X, Y, 1) * iw00 + lvl_D(I, dI, X + 1, Y, 1) * iw01 +
+                                   lvl_D(I, dI, X, Y + 1, 1) * iw10 +
+                                   lvl_D(I, dI, X + 1, Y + 1, 1) * iw11,
+                               W_BITS);
+        Iw[y * win + x] = (int16_t)ival;
+        dIw[(y * win + x) * 2] = (int16_t)ixval;
+        dIw[(y * win + x) * 2 + 1] = (int16_t)iyval;
+        if (acc_mode == ORC_ACC_FLOAT_SEQ) {
+          fA11 += (float)(ixval * ixval);
+          fA12 += (float)(ixval * iyval);
+          fA22 += (float)(iyval * iyval);
+        } else {
+          eA11 += (int64_t)ixval * ixval;
+          eA12 += (int64_t)ixval * iyval;
+          eA22 += (int64_t)iyval * iyval;
+        }
+      }
+    }
+    if (acc_mode != ORC_ACC_FLOAT_SEQ) {
+      fA11 = (float)eA11;
+      fA12 = (float)eA12;
+      fA22 = (float)eA22;
+    }
+    float A11 = fA11 * FLT_SCALE, A12 = fA12 * FLT_SCALE, A22 = fA22 * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) /
+                   (float)(2 * win * win);
+    if (minEig < min_eig_thr || D < FLT_EPSILON) {
+      if (level == 0) status[i] = 0;
+      continue;
+    }
+    D = 1.f / D;
+    nx -= half;
+    ny -= half;
+    float pdx = 0, pdy = 0;
+    for (int j = 0; j < max_count; j++) {
+      int inx = cv_floor_f(nx), iny = cv_floor_f(ny);
+      if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
+        if (level == 0) status[i] = 0;
+        break;
+      }
+      a = nx - inx;
+      b = ny - iny;
+      iw00 = cv_round_f((1.f - a) * (1.f - b) * (1 << W_BITS));
+      iw01 = cv_round_f(a * (1.f - b) * (1 << W_BITS));
+      iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
+      iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+      float fb1 = 0, fb2 = 0;
+      int64_t eb1 = 0, eb2 = 0;
+      for (int y = 0; y < win; y++) {
+        for (int x = 0; x < win; x++) {
+          const int X = inx + x, Y = iny + y;
+          int diff = CV_DESCALE(lvl_I(J, X, Y) * iw00 + lvl_I(J, X + 1, Y) * iw01 +
+                                    lvl_I(J, X, Y + 1) * iw10 + lvl_I(J, X + 1, Y + 1) * iw11,
+                                W_BITS - 5) -
+                     Iw[y * win + x];
+          if (acc_mode == ORC_ACC_FLOAT_SEQ) {
+            fb1 += (float)(diff * dIw[(y * win + x) * 2]);
+            fb2 += (float)(diff * dIw[(y * win + x) * 2 + 1]);
+          } else {
+            eb1 += (int64_t)diff * dIw[(y * win + x) * 2];
+            eb2 += (int64_t)diff * dIw[(y * win + x) * 2 + 1];
+          }
+        }
+      }
+      if (acc_mode != ORC_ACC_FLOAT_SEQ) {
+        fb1 = (float)eb1;
+        fb2 = (float)eb2;
+      }
+      float b1 = fb1 * FLT_SCALE, b2 = fb2 * FLT_SCALE;
+      float dx = (float)((A12 * b2 - A22 * b1) * D);
+      float dy = (float)((A12 * b1 - A11 * b2) * D);
+      nx += dx;
+      ny += dy;
+      next_pts[2 * i] = nx + half;
+      next_pts[2 * i + 1] = ny + half;
+      if ((double)dx * dx + (double)dy * dy <= epsilon) break;
+      if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+        next_pts[2 * i] -= dx * 0.5f;
+        next_pts[2 * i + 1] -= dy * 0.5f;
+        break;
+      }
+      pdx = dx;
+      pdy = dy;
+    }
+    /* default flags: err requested, OPTFLOW_LK_GET_MIN_EIGENVALS not set */
+    if (status[i] && err && level == 0) {
+      float fx = next_pts[2 * i] - half, fy = next_pts[2 * i + 1] - half;
+      int inx = cv_floor_f(fx), iny = cv_floor_f(fy);
+      if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
+        status[i] = 0;
+        continue;
+      }
+      float aa = fx - inx, bb = fy - iny;
+      iw00 = cv_round_f((1.f - aa) * (1.f - bb) * (1 << W_BITS));
+      iw01 = cv_round_f(aa * (1.f - bb) * (1 << W_BITS));
+      iw10 = cv_round_f((1.f - aa) * bb * (1 << W_BITS));
+      iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+      float errval = 0.f;
+      for (int y = 0; y < win; y++)
+        for (int x = 0; x < win; x++) {
+          const int X = inx + x, Y = iny + y;
+          int diff = CV_DESCALE(lvl_I(J, X, Y) * iw00 + lvl_I(J, X + 1, Y) * iw01 +
+                                    lvl_I(J, X, Y + 1) * iw10 + lvl_I(J, X + 1, Y + 1) * iw11,
+                                W_BITS - 5) -
+                     Iw[y * win + x];
+          errval += (float)abs(diff);
+        }
+      err[i] = errval * 1.f / (32 * win * win);
+    }
+  }
+}
+
+int orc_calc_optical_flow_pyr_lk(const uint8_t* prev, int prev_stride, const uint8_t* next,
+                                 int next_stride, int w, int h, const float* prev_pts,
+                                 float* next_pts, uint8_t* status, float* err, int n, int win,
+                                 int max_level, int max_count, double eps, double min_eig_thr,
+                                 int acc_mode) {
+  if (n <= 0) return 0;
+  /* cv: criteria clamp -- maxCount in [0,100], epsilon in [0,10], epsilon *= epsilon */
+  if (max_count < 0) max_count = 0;
+  if (max_count > 100) max_count = 100;
+  if (eps < 0.) eps = 0.;
+  if (eps > 10.) eps = 10.;
+  eps *= eps;
+
+  orc_pyramid P, N;
+  int ml = orc_build_pyramid(prev, w, h, prev_stride, win, max_level, &P);
+  int ml2 = orc_build_pyramid(next, w, h, next_stride, win, max_level, &N);
+  if (ml2 < ml) ml = ml2;
+  for (int i = 0; i < n; i++) {
+    status[i] = 1;
+    if (err) err[i] = 0;
+  }
+  int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)win * win * 3);
+  int16_t* dIw = Iw + (size_t)win * win;
+  int16_t* deriv = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)w * h);
+  for (int level = ml; level >= 0; level--) {
+    const orc_level* I = &P.lv[level];
+    orc_scharr_s16(I->data, I->w, I->h, I->w, deriv);
+    lk_level(I, deriv, &N.lv[level], prev_pts, next_pts, status, err, n, win, level, ml, max_count,
+             eps, min_eig_thr, acc_mode, Iw, dIw);
+  }
+  free(deriv);
+  free(Iw);
+  orc_free_pyramid(&P);
+  orc_free_pyramid(&N);
+  return ml;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cv: cornerMinEigenVal on a sub-matrix (ROI) of a parent image -- SURVEY A.1 steps 1-4       */
+/* ------------------------------------------------------------------------------------------ */
+/* Sobel reads the parent's real pixels outside the ROI and reflects only at the true image
+ * border.  Dx: row kernel [-1 0 1] (exact), column kernel [1 2 1]*scale as float32, evaluated
+ * (S[y-1]+S[y+1])*k1 + S[y]*k0 (cv: SymmColumnSmallFilter).  Dy: row kernel [1 2 1]*scale applied
+ * to the 8-bit source as k[0]*S[x-1]; += k[1]*S[x]; += k[2]*S[x+1] (cv: RowFilter<uchar,float>),
+ * column kernel [-1 0 1] (exact).
+ * Box filter: OpenCV's boxFilter accumulates 32F input in 64F (createBoxFilter: sumType=CV_64F),
+ * so the block sum is formed in double -- row sums left to right, then the column of row sums top
+ * to bottom -- and rounded to float32 once.  (SURVEY A.1 step 3 words this with float sums; the
+ * double form is what OpenCV does and makes the result independent of its running-sum order.)
+ * The box filter reflects (REFLECT_101) at the borders of the ROI's own covariance image. */
+void orc_corner_min_eigen_val(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
+                              int rw, int rh, int block_size, float* eig) {
+  const double scale_d = 1.0 / ((double)(1 << 2) * block_size * 255.0);
+  const float k_side = (float)(1.0 * scale_d), k_mid = (float)(2.0 * scale_d);
+  float* cov = (float*)malloc(sizeof(float) * 3 * (size_t)rw * rh);
+  for (int y = 0; y < rh; y++) {
+    const int Y = ry + y;
+    const int ym = reflect101(Y - 1, img_h), yp = reflect101(Y + 1, img_h);
+    for (int x = 0; x < rw; x++) {
+      const int X = rx + x;
+      const int xm = reflect101(X - 1, img_w), xp = reflect101(X + 1, img_w);
+      /* Dx */
+      const float r_m = (float)(img[(size_t)ym * stride + xp] - img[(size_t)ym * stride + xm]);
+      const float r_0 = (float)(img[(size_t)Y * stride + xp] - img[(size_t)Y * stride + xm]);
+      const float r_p = (float)(img[(size_t)yp * stride + xp] - img[(size_t)yp * stride + xm]);
+      const float dx = (r_m + r_p) * k_side + r_0 * k_mid;
+      /* Dy */
+      float s_m = k_side * (float)img[(size_t)ym * stride + xm];
+      s_m += k_mid * (float)img[(size_t)ym * stride + X];
+      s_m += k_side * (float)img[(size_t)ym * stride + xp];
+      float s_p = k_side * (float)img[(size_t)yp * stride + xm];
+      s_p += k_mid * (float)img[(size_t)yp * stride + X];
+      s_p += k_side * (float)img[(size_t)yp * stride + xp];
+      const float dy = s_p - s_m;
+      float* c = cov + ((size_t)y * rw + x) * 3;
+      c[0] = dx * dx;
+      c[1] = dx * dy;
+      c[2] = dy * dy;
+    }
+  }
+  const int a0 = -(block_size / 2); /* anchor = block/2: offsets a0 .. a0+block-1 */
+  for (int y = 0; y < rh; y++) {
+    for (int x = 0; x < rw; x++) {
+      double s[3] = {0, 0, 0};
+      for (int j = 0; j < block_size; j++) {
+        const int yy = reflect101(y + a0 + j, rh);
+        double r[3] = {0, 0, 0};
+        for (int i = 0; i < block_size; i++) {
+          const int xx = reflect101(x + a0 + i, rw);
+          const float* c = cov + ((size_t)yy * rw + xx) * 3;
+          if (i == 0) {
+            r[0] = (double)c[0];
+            r[1] = (double)c[1];
+            r[2] = (double)c[2];
+          } else {
+            r[0] += (double)c[0];
+            r[1] += (double)c[1];
+            r[2] += (double)c[2];
+          }
+        }
+        if (j == 0) {
+          s[0] = r[0];
+          s[1] = r[1];
+          s[2] = r[2];
+        } else {
+          s[0] += r[0];
+          s[1] += r[1];
+          s[2] += r[2];
+        }
+      }
+      const float a = (float)s[0] * 0.5f, b = (float)s[1], c = (float)s[2] * 0.5f;
+      eig[(size_t)y * rw + x] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+    }
+  }
+  free(cov);
+}
+
+/* cv: goodFeaturesToTrack -- SURVEY A.1 steps 5-9.  ROI of a parent image; mask (if any) is the
+ * matching ROI of the parent mask (mask points at the ROI origin).  Returns the corner count;
+ * out_xy holds ROI-relative integer-valued float coordinates. */
+typedef struct {
+  float v;
+  int idx;
+} orc_cand;
+
+static int cand_greater(const void* pa, const void* pb) {
+  const orc_cand* a = (const orc_cand*)pa;
+  const orc_cand* b = (const orc_cand*)pb;
+  /* cv: greaterThanPtr -- value descending, ties by larger address first */
+  if (a->v > b->v) return -1;
+  if (a->v < b->v) return 1;
+  return (a->idx > b->idx) ? -1 : (a->idx < b->idx ? 1 : 0);
+}
+
+int orc_good_features_to_track(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
+                               int rw, int rh, int max_corners, double quality, double min_dist,
+                               const uint8_t* mask, int mask_stride, int block_size, float* out_xy,
+                               int cap) {
+  if (rw <= 0 || rh <= 0) return 0;
+  float* eig = (float*)malloc(sizeof(float) * (size_t)rw * rh);
+  orc_corner_min_eigen_val(img, img_w, img_h, stride, rx, ry, rw, rh, block_size, eig);
+
+  /* cv: minMaxLoc(eig, 0, &maxVal, 0, 0, mask) */
+  double maxVal = 0;
+  int any = 0;
+  for (int y = 0; y < rh; y++)
+    for (int x = 0; x < rw; x++) {
+      if (mask && !mask[(size_t)y * mask_stride + x]) continue;
+      const double v = eig[(size_t)y * rw + x];
+      if (!any || v > maxVal) {
+        maxVal = v;
+        any = 1;
+      }
+    }
+  if (!any) maxVal = 0;
+  /* cv: threshold(eig, eig, maxVal*quality, 0, THRESH_TOZERO) */
+  const float thr = (float)(maxVal * quality);
+  for (size_t i = 0; i < (size_t)rw * rh; i++) eig[i] = eig[i] > thr ? eig[i] : 0.f;
+
+  /* cv: dilate 3x3 (outside ignored) + local-maximum test on the inner (rw-2)x(rh-2) pixels */
+  orc_cand* cand = (orc_cand*)malloc(sizeof(orc_cand) * ((size_t)rw * rh + 1));
+  int nc = 0;
+  for (int y = 1; y < rh - 1; y++)
+    for (int x = 1; x < rw - 1; x++) {
+      const float val = eig[(size_t)y * rw + x];
+      if (val == 0) continue;
+      float m = val;
+      for (int j = -1; j <= 1; j++)
+        for (int i = -1; i <= 1; i++) {
+          const float q = eig[(size_t)(y + j) * rw + (x + i)];
+          if (q > m) m = q;
+        }
+      if (val == m && (!mask || mask[(size_t)y * mask_stride + x])) {
+        cand[nc].v = val;
+        cand[nc].idx = y * rw + x;
+        nc++;
+      }
+    }
+  qsort(cand, (size_t)nc, sizeof(orc_cand), cand_greater);
+
+  int ncorners = 0;
+  if (nc > 0) {
+    if (min_dist >= 1) {
+      const int cell = cv_round_d(min_dist);
+      const int gw = (rw + cell - 1) / cell, gh = (rh + cell - 1) / cell;
+      /* buckets as linked lists over accepted corners */
+      int* head = (int*)malloc(sizeof(int) * (size_t)gw * gh);
+      int* nxt = (int*)malloc(sizeof(int) * ((size_t)nc + 1));
+      for (int i = 0; i < gw * gh; i++) head[i] = -1;
+      const double md2d = min_dist * min_dist; /* cv: minDistance *= minDistance (double) */
+      for (int i = 0; i < nc; i++) {
+        const int y = cand[i].idx / rw, x = cand[i].idx - y * rw;
+        int good = 1;
+        const int xc = x / cell, yc = y / cell;
+        int x1 = xc - 1, y1 = yc - 1, x2 = xc + 1, y2 = yc + 1;
+        if (x1 < 0) x1 = 0;
+        if (y1 < 0) y1 = 0;
+        if (x2 > gw - 1) x2 = gw - 1;
+        if (y2 > gh - 1) y2 = gh - 1;
+        for (int yy = y1; yy <= y2 && good; yy++)
+          for (int xx = x1; xx <= x2 && good; xx++)
+            for (int k = head[yy * gw + xx]; k >= 0; k = nxt[k]) {
+              const float ddx = (float)x - out_xy[2 * k], ddy = (float)y - out_xy[2 * k + 1];
+              /* cv: float dx*dx + dy*dy compared with the double minDistance^2 */
+              if ((double)(ddx * ddx + ddy * ddy) < md2d) {
+                good = 0;
+                break;
+              }
+            }
+        if (good) {
+          if (ncorners >= cap) break;
+          out_xy[2 * ncorners] = (float)x;
+          out_xy[2 * ncorners + 1] = (float)y;
+          nxt[ncorners] = head[yc * gw + xc];
+          head[yc * gw + xc] = ncorners;
+          ncorners++;
+          if (max_corners > 0 && ncorners == max_corners) break;
+        }
+      }
+      free(head);
+      free(nxt);
+    } else {
+      for (int i = 0; i < nc; i++) {
+        if (ncorners >= cap) break;
+        const int y = cand[i].idx / rw, x = cand[i].idx - y * rw;
+        out_xy[2 * ncorners] = (float)x;
+        out_xy[2 * ncorners + 1] = (float)y;
+        ncorners++;
+        if (max_corners > 0 && ncorners == max_corners) break;
+      }
+    }
+  }
+  free(cand);
+  free(eig);
+  return ncorners;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* reference wrapper: FeatureDetectorShiTomasiBucketing                                        */
+/* ------------------------------------------------------------------------------------------ */
+/* ref: src/vslam/feature/FeatureDetectorShiTomasiBucketing.cpp:38-48 (ctor; index starts at 0) */
+void orc_detector_init(orc_detector* d, int32_t rows, int32_t cols, int32_t max_features,
+                       double min_distance) {
+  d->division_number_row = rows;
+  d->division_number_col = cols;
+  d->max_feature_number = max_features;
+  d->min_feature_distance = min_distance;
+  d->max_feature_index = 0;
+}
+
+/* ref: FeatureDetectorShiTomasiBucketing.cpp:13-36 (GenerateGrid, column-major, Rect2f) and
+ * :144-149 (Rect2f -> Rect conversion = cv::saturate_cast<int>(float) = cvRound on x, y, width,
+ * height independently).  Returns the number of cells. */
+int orc_generate_grid(int w, int h, int cols, int rows, int* rects, float* origin) {
+  const double dx = (double)w / (double)cols, dy = (double)h / (double)rows;
+  int k = 0;
+  for (int x = 0; x < cols; x++)
+    for (int y = 0; y < rows; y++) {
+      const float lx = (float)(x * dx), ly = (float)(y * dy);
+      const float rxf = lx + (float)dx, ryf = ly + (float)dy; /* Point2f + Point2f */
+      const float wf = rxf - lx, hf = ryf - ly;               /* Rect2f(pt1, pt2) */
+      rects[4 * k + 0] = cv_round_f(lx);
+      rects[4 * k + 1] = cv_round_f(ly);
+      rects[4 * k + 2] = cv_round_f(wf);
+      rects[4 * k + 3] = cv_round_f(hf);
+      if (origin) { /* Rect2f::x, ::y -- what :169 adds to the cell-local corner */
+        origin[2 * k] = lx;
+        origin[2 * k + 1] = ly;
+      }
+      k++;
+    }
+  return k;
+}
+
+/* ref: FeatureDetectorShiTomasiBucketing.cpp:67-239 (DetectShiTomasiCorners).  SoA in/out:
+ * ids/xy/age hold *n_inout entries on entry; new features are upserted (an id that already exists
+ * is overwritten in place, exactly like unordered_map::operator[]), others appended.
+ * Returns 0, or -1 when capacity is exhausted, -2 when a cell rectangle leaves the image
+ * (cv::Mat::operator() would throw). */
+int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int stride,
+                        const uint8_t* mask, int mask_stride, uint64_t* ids, double* xy,
+                        uint32_t* age, int* n_inout, int capacity) {
+  const int n0 = *n_inout;
+  int n = n0;
+  const int cols = d->division_number_col, rows = d->division_number_row;
+  const int ncell = cols * rows;
+  int* rects = (int*)malloc(sizeof(int) * 4 * (size_t)ncell);
+  float* origin = (float*)malloc(sizeof(float) * 2 * (size_t)ncell);
+  orc_generate_grid(w, h, cols, rows, rects, origin); /* :114-115 */
+  const int grid_max = d->max_feature_number / (rows * cols); /* :116-117 */
+
+  /* :120-129 flag image; every pre-existing feature is a kd-tree point (brute force here: only
+   * the nearest distance is used, kdtree/KDTree.cpp:154-233 is an exact NN search) */
+  uint8_t* flag = (uint8_t*)calloc((size_t)w * h, 1);
+  for (int i = 0; i < n0; i++) {
+    const double px = xy[2 * i], py = xy[2 * i + 1];
+    if (px > 0 && px < w && py > 0 && py < h) flag[(size_t)((int)py) * w + (int)px] = 1;
+  }
+
+  int rc = 0;
+  uint64_t feature_index = d->max_feature_index; /* :142 */
+  float* pts = (float*)malloc(sizeof(float) * 2 * (size_t)(grid_max > 0 ? grid_max : 1));
+  for (int c = 0; c < ncell; c++) {
+    const int rx = rects[4 * c], ry = rects[4 * c + 1], rw = rects[4 * c + 2],
+              rh = rects[4 * c + 3];
+    if (rx < 0 || ry < 0 || rw < 0 || rh < 0 || rx + rw > w || ry + rh > h) {
+      rc = -2;
+      break;
+    }
+    int num = 0; /* :152 countNonZero */
+    for (int y = 0; y < rh; y++)
+      for (int x = 0; x < rw; x++) num += flag[(size_t)(ry + y) * w + rx + x] != 0;
+    const int query = grid_max - num;
+    if (query <= 0) break; /* :154 -- break, not continue */
+    const uint8_t* m = mask ? mask + (size_t)ry * mask_stride + rx : NULL;
+    const int got = orc_good_features_to_track(img, w, h, stride, rx, ry, rw, rh, query, 0.1,
+                                               d->min_feature_distance, m, mask_stride, 3, pts,
+                                               grid_max); /* :158-163 */
+    for (int k = 0; k < got; k++) { /* :168-230 */
+      /* :169 kp.pt.x + grect.x: float + float with the UNROUNDED Rect2f origin */
+      const double cx = (double)(pts[2 * k] + origin[2 * c]);
+      const double cy = (double)(pts[2 * k + 1] + origin[2 * c + 1]);
+      int accept = 1;
+      if (n0 > 0) {
+        double best = 0;
+        for (int i = 0; i < n0; i++) {
+          const double ddx = cx - xy[2 * i], ddy = cy - xy[2 * i + 1];
+          const double d2 = ddx * ddx + ddy * ddy;
+          if (i == 0 || d2 < best) best = d2;
+        }
+        accept = sqrt(best) > d->min_feature_distance; /* :178-180 strict > on the L2 norm */
+      }
+      if (accept) {
+        int slot = -1;
+        for (int i = 0; i < n; i++)
+          if (ids[i] == feature_index) {
+            slot = i;
+            break;
+          }
+        if (slot < 0) {
+          if (n >= capacity) {
+            rc = -1;
+            break;
+          }
+          slot = n++;
+        }
+        ids[slot] = feature_index;
+        xy[2 * slot] = cx;
+        xy[2 * slot + 1] = cy;
+        age[slot] = 1;
+        feature_index++;
+      }
+    }
+    if (rc) break;
+  }
+  d->max_feature_index = feature_index - 1; /* :238 */
+  *n_inout = n;
+  free(pts);
+  free(flag);
+  free(origin);
+  free(rects);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* reference wrapper: FeatureTrackerLucasKanade                                                */
+/* ------------------------------------------------------------------------------------------ */
+/* ref: src/vslam/feature/FeatureTrackerLucasKanade.cpp:8-23 */
+void orc_tracker_init(orc_tracker* t, int32_t max_iter, double eps, int32_t win, int32_t max_level,
+                      double backtrack_thr, int acc_mode) {
+  memset(t, 0, sizeof(*t));
+  t->klt_max_iteration = max_iter;
+  t->klt_epsilon = eps;
+  t->klt_window_size = win;
+  t->klt_max_level = max_level;
+  t->backtrack_distance_threshold = backtrack_thr;
+  t->acc_mode = acc_mode;
+}
+
+void orc_tracker_free(orc_tracker* t) {
+  free(t->old_image);
+  t->old_image = NULL;
+}
+
+/* ref: FeatureTrackerLucasKanade.cpp:187-240 (TrackByLucasKanade): flatten, calcOpticalFlowPyrLK,
+ * keep status==1.  Works on compacted SoA arrays in place; returns the kept count.
+ * `keep_idx[k]` = index into the input arrays of the k-th kept feature. */
+static int track_by_lk(const orc_tracker* t, const uint8_t* prev, int prev_stride,
+                       const uint8_t* cur, int cur_stride, int w, int h, const double* xy_in, int n,
+                       double* xy_out, int* keep_idx) {
+  if (n == 0) return 0; /* :195-198 empty inputs: untouched */
+  float* pp = (float*)malloc(sizeof(float) * 2 * (size_t)n * 2);
+  float* np_ = pp + 2 * (size_t)n;
+  uint8_t* st = (uint8_t*)malloc((size_t)n);
+  float* er = (float*)malloc(sizeof(float) * (size_t)n);
+  for (int i = 0; i < n; i++) { /* :208-211 double -> float narrowing */
+    pp[2 * i] = (float)xy_in[2 * i];
+    pp[2 * i + 1] = (float)xy_in[2 * i + 1];
+    np_[2 * i] = np_[2 * i + 1] = 0.f;
+  }
+  orc_calc_optical_flow_pyr_lk(prev, prev_stride, cur, cur_stride, w, h, pp, np_, st, er, n,
+                               t->klt_window_size, t->klt_max_level, t->klt_max_iteration,
+                               t->klt_epsilon, 1e-4, t->acc_mode); /* :216-224 */
+  int m = 0;
+  for (int i = 0; i < n; i++)
+    if (st[i] == 1) { /* :229-235 */
+      xy_out[2 * m] = (double)np_[2 * i];
+      xy_out[2 * m + 1] = (double)np_[2 * i + 1];
+      keep_idx[m] = i;
+      m++;
+    }
+  free(er);
+  free(st);
+  free(pp);
+  return m;
+}
+
+/* ref: FeatureTrackerLucasKanade.cpp:109-185 (4-arg Track) */
+int orc_tracker_track_pair(const orc_tracker* t, const uint8_t* prev, int prev_stride,
+                           const uint8_t* cur, int cur_stride, int w, int h, uint64_t* ids,
+                           double* xy, uint32_t* age, int* n_inout, orc_track_stats* stats) {
+  const int n = *n_inout;
+  orc_track_stats s = {n, 0, 0, 0};
+  double* fwd = (double*)malloc(sizeof(double) * 2 * (size_t)(n + 1) * 2);
+  double* back = fwd + 2 * (size_t)(n + 1);
+  int* fidx = (int*)malloc(sizeof(int) * (size_t)(n + 1) * 2);
+  int* bidx = fidx + (n + 1);
+  const int nf = track_by_lk(t, prev, prev_stride, cur, cur_stride, w, h, xy, n, fwd, fidx);
+  s.forward = nf;
+  const int nb = track_by_lk(t, cur, cur_stride, prev, prev_stride, w, h, fwd, nf, back, bidx);
+  s.backward = nb;
+  int m = 0;
+  for (int k = 0; k < nb; k++) { /* :155-160 */
+    const int f = bidx[k];  /* index into forward arrays */
+    const int o = fidx[f];  /* index into the original arrays */
+    const double ddx = back[2 * k] - xy[2 * o], ddy = back[2 * k + 1] - xy[2 * o + 1];
+    if (sqrt(ddx * ddx + ddy * ddy) <= t->backtrack_distance_threshold) {
+      /* o is increasing in k, and m <= o, so the in-place compaction is safe */
+      ids[m] = ids[o];
+      age[m] = age[o];
+      fidx[m] = f;
+      m++;
+    }
+  }
+  for (int k = 0; k < m; k++) {
+    xy[2 * k] = fwd[2 * fidx[k]];
+    xy[2 * k + 1] = fwd[2 * fidx[k] + 1];
+  }
+  s.verified = m;
+  *n_inout = m;
+  if (stats) *stats = s;
+  free(fidx);
+  free(fwd);
+  return 0;
+}
+
+/* ref: FeatureTrackerLucasKanade.cpp:25-107 (3-arg stateful Track).  The reference keeps a
+ * shallow reference to the caller's frame; this copy is value-equivalent. */
+int orc_tracker_track(orc_tracker* t, const uint8_t* cur, int w, int h, int stride, uint64_t* ids,
+                      double* xy, uint32_t* age, int* n_inout, orc_track_stats* stats) {
+  int rc = 0;
+  if (t->old_image == NULL) { /* :29-32 */
+    if (stats) {
+      stats->input = *n_inout;
+      stats->forward = stats->backward = stats->verified = *n_inout;
+    }
+  } else {
+    if (t->old_w != w || t->old_h != h) return -3;
+    rc = orc_tracker_track_pair(t, t->old_image, w, cur, stride, w, h, ids, xy, age, n_inout,
+                                stats);
+  }
+  if (t->old_image == NULL || t->old_w != w || t->old_h != h) {
+    free(t->old_image);
+    t->old_image = (uint8_t*)malloc((size_t)w * h);
+    t->old_w = w;
+    t->old_h = h;
+  }
+  for (int y = 0; y < h; y++) memcpy(t->old_image + (size_t)y * w, cur + (size_t)y * stride, w);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* timed CPU baseline: one frontend step (Track, then UpdateDetection) on independent streams   */
+/* ------------------------------------------------------------------------------------------ */
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+int orc_step_streams(orc_tracker* trackers, orc_detector* detectors, int streams,
+                     const uint8_t* frames, long frame_stride_bytes, int w, int h, int stride,
+                     uint64_t* ids, double* xy, uint32_t* age, int* n, int capacity) {
+  int rc_all = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int s = 0; s < streams; s++) {
+    const uint8_t* f = frames + (size_t)s * frame_stride_bytes;
+    uint64_t* sid = ids + (size_t)s * capacity;
+    double* sxy = xy + 2 * (size_t)s * capacity;
+    uint32_t* sage = age + (size_t)s * capacity;
+    int rc = orc_tracker_track(&trackers[s], f, w, h, stride, sid, sxy, sage, &n[s], NULL);
+    if (!rc)
+      rc = orc_detector_update(&detectors[s], f, w, h, stride, NULL, 0, sid, sxy, sage, &n[s],
+                               capacity);
+    if (rc) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+      rc_all = rc;
+    }
+  }
+  return rc_all;
+}

@@ -1,0 +1,126 @@
+/*
+ * vsf_oracle.h -- CPU ORACLE for the vision-frontend hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the algorithm the reference (eryeden/vi-slam) runs on the CPU
+ * for image pyramid -> Shi-Tomasi grid detection -> pyramidal LK tracking with forward-backward
+ * check.  It is used ONLY by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg as
+ * the checker / reported baseline.  The product path (vi-slam_amd/csrc) never links or calls it.
+ *
+ * PARITY UNPINNED.  The reference does none of this arithmetic itself: its detector and tracker
+ * call OpenCV 3.4.9 (docs/setup.md:27; call sites FeatureDetectorShiTomasiBucketing.cpp:158-163,
+ * FeatureTrackerLucasKanade.cpp:216-224).  OpenCV is a third-party dependency that is not vendored
+ * under /root/reference and is not installed here, and the reference's own tests are placeholders
+ * (test/sample/test_sample1.cpp:38-45), so no golden vector of the reference pins these results.
+ * The OpenCV parts below restate the published OpenCV 3.4 algorithms (imgproc: pyrDown, Sobel,
+ * boxFilter, cornerMinEigenVal, goodFeaturesToTrack; video: buildOpticalFlowPyramid,
+ * calcOpticalFlowPyrLK scalar path) per SURVEY.md Appendix A; the wrapper parts follow the
+ * reference's own sources line by line (citations at each function in vsf_oracle.c).
+ * What pins it instead: analytic known-answer tests (tests/test_oracle_known_answers.py) and
+ * committed golden vectors generated from this file (tests/golden/, tests/golden/make_golden.py).
+ */
+#ifndef VSF_ORACLE_H
+#define VSF_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_LEVELS 16
+
+/* LK accumulation modes for sum(Ix*Ix) etc. (lines marked with a warning sign):
+ *   ORC_ACC_FLOAT_SEQ : float32 accumulator, raster order, (float)(int product) per pixel.  This is
+ *                       OpenCV 3.4's scalar (non-SIMD) path, the "restated reference".
+ *   ORC_ACC_EXACT     : exact integer sum, converted to float32 once (round-to-nearest-even).
+ *                       Order independent, so a parallel implementation can match it bit for bit.
+ * tests/test_oracle_lk_modes.py measures the distance between the two modes (<= 0.01 px, same
+ * status) so that a bit-exact match against ORC_ACC_EXACT carries over to the reference order
+ * within the tolerance BASELINE.json states. */
+#define ORC_ACC_FLOAT_SEQ 0
+#define ORC_ACC_EXACT 1
+
+typedef struct {
+  int w, h;
+  uint8_t* data; /* dense, stride == w */
+} orc_level;
+
+typedef struct {
+  int max_level; /* effective maxLevel (levels 0..max_level are valid) */
+  orc_level lv[ORC_MAX_LEVELS];
+} orc_pyramid;
+
+/* ---- OpenCV imgproc / video restatements ---- */
+void orc_pyr_down_u8(const uint8_t* src, int w, int h, int stride, uint8_t* dst);
+int orc_build_pyramid(const uint8_t* img, int w, int h, int stride, int win, int max_level,
+                      orc_pyramid* out);
+void orc_free_pyramid(orc_pyramid* p);
+void orc_scharr_s16(const uint8_t* src, int w, int h, int stride, int16_t* dxy);
+
+int orc_calc_optical_flow_pyr_lk(const uint8_t* prev, int prev_stride, const uint8_t* next,
+                                 int next_stride, int w, int h, const float* prev_pts,
+                                 float* next_pts, uint8_t* status, float* err, int n, int win,
+                                 int max_level, int max_count, double eps, double min_eig_thr,
+                                 int acc_mode);
+
+void orc_corner_min_eigen_val(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
+                              int rw, int rh, int block_size, float* eig);
+
+int orc_good_features_to_track(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
+                               int rw, int rh, int max_corners, double quality, double min_dist,
+                               const uint8_t* mask, int mask_stride, int block_size, float* out_xy,
+                               int cap);
+
+/* ---- reference wrappers ---- */
+typedef struct {
+  int32_t division_number_row;
+  int32_t division_number_col;
+  int32_t max_feature_number;
+  double min_feature_distance;
+  uint64_t max_feature_index;
+} orc_detector;
+
+void orc_detector_init(orc_detector* d, int32_t rows, int32_t cols, int32_t max_features,
+                       double min_distance);
+int orc_generate_grid(int w, int h, int cols, int rows, int* rects /* 4*cells: x,y,w,h */,
+                      float* origin /* 2*cells Rect2f x,y; may be NULL */);
+int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int stride,
+                        const uint8_t* mask, int mask_stride, uint64_t* ids, double* xy,
+                        uint32_t* age, int* n_inout, int capacity);
+
+typedef struct {
+  int32_t klt_max_iteration;
+  double klt_epsilon;
+  int32_t klt_window_size;
+  int32_t klt_max_level;
+  double backtrack_distance_threshold;
+  int acc_mode;
+  uint8_t* old_image; /* owned copy; NULL == cv::Mat::empty() */
+  int old_w, old_h;
+} orc_tracker;
+
+typedef struct {
+  int32_t input, forward, backward, verified;
+} orc_track_stats;
+
+void orc_tracker_init(orc_tracker* t, int32_t max_iter, double eps, int32_t win, int32_t max_level,
+                      double backtrack_thr, int acc_mode);
+void orc_tracker_free(orc_tracker* t);
+int orc_tracker_track(orc_tracker* t, const uint8_t* cur, int w, int h, int stride, uint64_t* ids,
+                      double* xy, uint32_t* age, int* n_inout, orc_track_stats* stats);
+int orc_tracker_track_pair(const orc_tracker* t, const uint8_t* prev, int prev_stride,
+                           const uint8_t* cur, int cur_stride, int w, int h, uint64_t* ids,
+                           double* xy, uint32_t* age, int* n_inout, orc_track_stats* stats);
+
+/* One frontend step on `streams` independent streams, used as the timed CPU baseline:
+ * track (3-arg) then detect on the same frame.  Parallel over streams with OpenMP when built
+ * with -fopenmp (threads = omp default), serial otherwise. */
+int orc_step_streams(orc_tracker* trackers, orc_detector* detectors, int streams,
+                     const uint8_t* frames, long frame_stride_bytes, int w, int h, int stride,
+                     uint64_t* ids, double* xy, uint32_t* age, int* n, int capacity);
+int orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
