@@ -1,0 +1,168 @@
+/*
+ * vsf.h -- C ABI of the MI355X-native vision-frontend hot path (libvsf_hip.so).
+ *
+ * Drop-in boundary for the reference's two C++ interfaces (eryeden/vi-slam, paths relative to the
+ * reference root):
+ *   vslam::feature::FeatureDetectorBase::UpdateDetection   src/vslam/feature/FeatureDetectorBase.hpp:17-20
+ *   vslam::feature::FeatureTrackerBase::Track              src/vslam/feature/FeatureTrackerBase.hpp:21-23
+ * as implemented by FeatureDetectorShiTomasiBucketing (FeatureDetectorShiTomasiBucketing.cpp:38-239)
+ * and FeatureTrackerLucasKanade (FeatureTrackerLucasKanade.cpp:8-240).
+ *
+ * The reference's in/out containers FeaturePositionDatabase / FeatureAgeDatabase
+ * (src/vslam/type_defines.hpp:95-99: unordered_map<uint64, Vector2d>, unordered_map<uint64,uint32>
+ * with one key set) cross this boundary as SoA arrays: ids[n] (uint64), xy[2n] (double, x then y),
+ * age[n] (uint32).  Order is not significant (the reference's maps are unordered); this library
+ * keeps surviving entries in their input order and appends new ones in id order.
+ *
+ * Plain pointers and sizes only; no C++/torch types.  Every call returns VSF_OK (0) or a negative
+ * VSF_E_* code; nothing throws.  A context is not thread-safe (the reference objects are not
+ * either: old_image_, max_feature_index_); use one context per thread.  All kernels are hand
+ * written HIP for gfx950; there is no CPU fallback: without a GPU vsf_create fails.
+ */
+#ifndef VSF_H
+#define VSF_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VSF_OK 0
+#define VSF_E_INVALID (-1)   /* bad argument / parameter out of the supported range */
+#define VSF_E_HIP (-2)       /* a HIP runtime call failed (see vsf_last_error) */
+#define VSF_E_CAPACITY (-3)  /* feature table capacity exhausted */
+#define VSF_E_GEOMETRY (-4)  /* frame size differs from the context's, or a grid cell leaves the image
+                                (cv::Mat::operator()(Rect) would throw in the reference) */
+#define VSF_E_NOMEM (-5)
+
+typedef struct vsf_ctx vsf_ctx;
+
+/* Parameters = the constructor arguments of the two reference classes plus the OpenCV defaults
+ * the reference relies on. */
+typedef struct vsf_params {
+  /* FeatureDetectorShiTomasiBucketing ctor (FeatureDetectorShiTomasiBucketing.hpp:32-35) */
+  int32_t grid_rows;      /* division_number_row */
+  int32_t grid_cols;      /* division_number_col */
+  int32_t max_features;   /* max_feature_number  */
+  double min_distance;    /* min_feature_distance */
+  double quality_level;   /* 0.1, hard-coded at FeatureDetectorShiTomasiBucketing.cpp:161 */
+  int32_t block_size;     /* 3, cv::goodFeaturesToTrack default */
+  /* FeatureTrackerLucasKanade ctor (FeatureTrackerLucasKanade.hpp:19-23) */
+  int32_t klt_max_iter;   /* klt_max_iteration */
+  double klt_eps;         /* klt_epsilon */
+  int32_t klt_win;        /* klt_window_size (square), 3..32 */
+  int32_t klt_max_level;  /* klt_max_level, 0..7 */
+  double min_eig_thr;     /* 1e-4, cv::calcOpticalFlowPyrLK default */
+  double backtrack_thr;   /* backtrack_distance_threshold */
+  /* geometry and sizing of this context */
+  int32_t width, height;  /* frame size (8-bit, single channel) */
+  int32_t streams;        /* independent streams held by this context (>= 1) */
+  int32_t capacity;       /* feature-table capacity per stream; 0 = max_features + 64 */
+  int32_t device_id;      /* HIP device ordinal */
+} vsf_params;
+
+/* The three counts FeatureTrackerLucasKanade::Track logs (FeatureTrackerLucasKanade.cpp:87-104). */
+typedef struct vsf_track_stats {
+  int32_t input, forward, backward, verified;
+} vsf_track_stats;
+
+/* Fills *p with the reference's example parameters (example_feature_detection_and_tracking.cpp:19-23
+ * grid 4x4 / 300 features, OpenCV's 21x21 window, 4 levels, 30 iterations, eps 0.01) at 752x480. */
+void vsf_default_params(vsf_params* p);
+
+int vsf_create(const vsf_params* p, vsf_ctx** out);
+void vsf_destroy(vsf_ctx* ctx);
+const char* vsf_last_error(const vsf_ctx* ctx);
+const char* vsf_version(void);
+
+/* ---- single-stream host-pointer API: the drop-in for the reference interfaces (uses stream 0) ---- */
+
+/* FeatureTrackerLucasKanade::Track, 3-argument stateful form (FeatureTrackerLucasKanade.cpp:25-107).
+ * The first call only stores the frame and leaves the table untouched (:29-32).  The frame is
+ * copied to the device during the call (the reference keeps a shallow cv::Mat reference instead).
+ * stats may be NULL. */
+int vsf_track(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride, uint64_t* ids,
+              double* xy, uint32_t* age, int32_t* n_inout, vsf_track_stats* stats);
+
+/* 4-argument stateless form (FeatureTrackerLucasKanade.cpp:109-185). */
+int vsf_track_pair(vsf_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const uint8_t* cur,
+                   int32_t cur_stride, int32_t w, int32_t h, uint64_t* ids, double* xy,
+                   uint32_t* age, int32_t* n_inout, vsf_track_stats* stats);
+
+/* FeatureDetectorShiTomasiBucketing::UpdateDetection (FeatureDetectorShiTomasiBucketing.cpp:50-239)
+ * including its quirks (column-major cells, early break, id counter), without
+ * the cv::imshow side effect.  mask may be NULL (no mask); non-zero = allowed.  `capacity` is the
+ * length of the caller's arrays. */
+int vsf_detect(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
+               const uint8_t* mask, int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age,
+               int32_t* n_inout, int32_t capacity);
+
+/* max_feature_index_ of the detector (FeatureDetectorShiTomasiBucketing.hpp:53). */
+int vsf_get_max_feature_index(vsf_ctx* ctx, int32_t stream, uint64_t* out);
+int vsf_set_max_feature_index(vsf_ctx* ctx, int32_t stream, uint64_t value);
+
+/* ---- batched device-resident API (multi-stream configs; frames already in HBM) ----
+ * d_frames points to `streams` frames in device memory, frame s at d_frames + s*frame_stride_bytes,
+ * rows `row_stride` bytes apart.  Frames are BORROWED: a batch passed to vsf_batch_track /
+ * vsf_batch_step must stay valid and unmodified until the next such call has completed, because it
+ * is level 0 of the "previous" pyramid of that next call (the reference holds the previous cv::Mat
+ * the same way, FeatureTrackerLucasKanade.cpp:30,106).  `hip_stream` is a hipStream_t (NULL = the
+ * default stream); calls only enqueue work and do not synchronise. */
+int vsf_batch_track(vsf_ctx* ctx, const uint8_t* d_frames, int64_t frame_stride_bytes,
+                    int32_t row_stride, void* hip_stream);
+int vsf_batch_detect(vsf_ctx* ctx, const uint8_t* d_frames, int64_t frame_stride_bytes,
+                     int32_t row_stride, const uint8_t* d_masks, int64_t mask_stride_bytes,
+                     int32_t mask_row_stride, void* hip_stream);
+/* One frontend step per stream: Track, then UpdateDetection on the same frame. */
+int vsf_batch_step(vsf_ctx* ctx, const uint8_t* d_frames, int64_t frame_stride_bytes,
+                   int32_t row_stride, void* hip_stream);
+
+/* Host <-> device copies of the feature tables of streams [first, first+count).  Arrays are
+ * [count][capacity] (xy: [count][capacity][2]); n is [count].  Synchronous. */
+int vsf_batch_upload(vsf_ctx* ctx, int32_t first, int32_t count, const uint64_t* ids,
+                     const double* xy, const uint32_t* age, const int32_t* n);
+int vsf_batch_download(vsf_ctx* ctx, int32_t first, int32_t count, uint64_t* ids, double* xy,
+                       uint32_t* age, int32_t* n, vsf_track_stats* stats /* [count] or NULL */);
+/* Device pointers of the resident tables (for a collective over xGMI): ids [streams][capacity]
+ * u64, xy [streams][capacity][2] f64, age [streams][capacity] u32, n [streams] i32. */
+int vsf_batch_device_tables(vsf_ctx* ctx, void** ids, void** xy, void** age, void** n,
+                            int32_t* capacity);
+/* Sticky per-stream device status of the batched calls: 0 or VSF_E_CAPACITY.  Synchronous. */
+int vsf_batch_status(vsf_ctx* ctx, int32_t* status /* [streams] */);
+/* Forget the previous frame (next vsf_batch_track / vsf_track only stores its frame). */
+int vsf_reset_tracker(vsf_ctx* ctx);
+
+/* ---- building blocks exposed for parity tests (synchronous, stream 0, host pointers) ---- */
+/* OpenCV buildOpticalFlowPyramid levels; out_levels[l] receives level l densely (w_l*h_l bytes),
+ * l = 1..*max_level_out; returns the effective maxLevel in *max_level_out. */
+int vsf_debug_pyramid(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
+                      uint8_t** out_levels, int32_t* max_level_out);
+/* cv::calcOpticalFlowPyrLK on n points (status as OpenCV: 1 = found). */
+int vsf_debug_lk(vsf_ctx* ctx, const uint8_t* prev, const uint8_t* next, int32_t w, int32_t h,
+                 const float* prev_pts, float* next_pts, uint8_t* status, int32_t n);
+/* cv::cornerMinEigenVal of grid cell `cell` (column-major index): out receives the dense
+ * [cell_h][cell_w] map (at most w*h floats), rect (may be NULL) the cell's x, y, w, h. */
+int vsf_debug_min_eig(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
+                      int32_t cell, float* out, int32_t* rect);
+
+/* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py ---- */
+#define VSF_K_PYRAMID 0
+#define VSF_K_LK 1
+#define VSF_K_COMPACT 2
+#define VSF_K_OCCUPANCY 3
+#define VSF_K_SCORE 4
+#define VSF_K_CANDIDATES 5
+#define VSF_K_SELECT 6
+#define VSF_K_APPEND 7
+#define VSF_K_COUNT 8
+int vsf_profile_enable(vsf_ctx* ctx, int32_t on);
+/* Sums the recorded event pairs: total milliseconds and launch count per kernel id.  Synchronous;
+ * clears the record. */
+int vsf_profile_read(vsf_ctx* ctx, float* total_ms /* [VSF_K_COUNT] */,
+                     int32_t* launches /* [VSF_K_COUNT] */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

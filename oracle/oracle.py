@@ -122,7 +122,7 @@ def calc_optical_flow_pyr_lk(prev, nxt, pts, win=21, max_level=3, max_count=30, 
 def corner_min_eigen_val(img, roi=None, block_size=3):
     img = _img(img)
     h, w = img.shape
-    rx, ry, rw, rh = roi if roi is not None else (0, 0, w, h)
+    rx, ry, rw, rh = [int(v) for v in (roi if roi is not None else (0, 0, w, h))]
     out = np.empty((rh, rw), np.float32)
     lib().orc_corner_min_eigen_val(img.ctypes.data_as(C.c_void_p), w, h, w, rx, ry, rw, rh,
                                    block_size, out.ctypes.data_as(C.c_void_p))
@@ -133,7 +133,7 @@ def good_features_to_track(img, max_corners, quality, min_dist, roi=None, mask=N
                            block_size=3):
     img = _img(img)
     h, w = img.shape
-    rx, ry, rw, rh = roi if roi is not None else (0, 0, w, h)
+    rx, ry, rw, rh = [int(v) for v in (roi if roi is not None else (0, 0, w, h))]
     cap = max(rw * rh, 1)
     out = np.zeros((cap, 2), np.float32)
     mptr, mstride = None, 0

@@ -1,0 +1,311 @@
+"""vi-slam_amd: MI355X-native vision-frontend hot path (pyramid -> Shi-Tomasi grid detect -> KLT).
+
+This package is a thin ctypes binding of the C ABI in include/vsf.h (libvsf_hip.so, hand-written
+HIP kernels for gfx950) plus Python mirrors of the two reference classes the path sits behind
+(vslam::feature::FeatureDetectorShiTomasiBucketing / FeatureTrackerLucasKanade).  There is no CPU
+fallback: loading fails loudly when the HIP library is missing, and creating a context fails
+without a GPU.  The directory name carries a '-', so import it with `load_package()` from
+repo-root helpers (tests/conftest.py, bench.py, __graft_entry__.py) under the name `vi_slam_amd`.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvsf_hip.so")
+
+VSF_OK = 0
+VSF_E_INVALID, VSF_E_HIP, VSF_E_CAPACITY, VSF_E_GEOMETRY, VSF_E_NOMEM = -1, -2, -3, -4, -5
+KERNEL_NAMES = ["pyramid", "lk", "compact", "occupancy", "score", "candidates", "select", "append"]
+
+# every symbol include/vsf.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = [
+    "vsf_default_params", "vsf_create", "vsf_destroy", "vsf_last_error", "vsf_version",
+    "vsf_track", "vsf_track_pair", "vsf_detect", "vsf_get_max_feature_index",
+    "vsf_set_max_feature_index", "vsf_batch_track", "vsf_batch_detect", "vsf_batch_step",
+    "vsf_batch_upload", "vsf_batch_download", "vsf_batch_device_tables", "vsf_batch_status",
+    "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig",
+    "vsf_profile_enable", "vsf_profile_read",
+]
+
+
+class VsfParams(C.Structure):
+    _fields_ = [
+        ("grid_rows", C.c_int32), ("grid_cols", C.c_int32), ("max_features", C.c_int32),
+        ("min_distance", C.c_double), ("quality_level", C.c_double), ("block_size", C.c_int32),
+        ("klt_max_iter", C.c_int32), ("klt_eps", C.c_double), ("klt_win", C.c_int32),
+        ("klt_max_level", C.c_int32), ("min_eig_thr", C.c_double), ("backtrack_thr", C.c_double),
+        ("width", C.c_int32), ("height", C.c_int32), ("streams", C.c_int32),
+        ("capacity", C.c_int32), ("device_id", C.c_int32),
+    ]
+
+
+class VsfTrackStats(C.Structure):
+    _fields_ = [("input", C.c_int32), ("forward", C.c_int32), ("backward", C.c_int32),
+                ("verified", C.c_int32)]
+
+
+class VsfError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("vsf error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Loads libvsf_hip.so; raises if the HIP extension has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("HIP extension missing: %s (run __graft_entry__.build())" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.vsf_last_error.restype = C.c_char_p
+        L.vsf_version.restype = C.c_char_p
+        L.vsf_last_error.argtypes = [C.c_void_p]
+        L.vsf_destroy.argtypes = [C.c_void_p]
+        L.vsf_destroy.restype = None
+        _lib = L
+    return _lib
+
+
+def default_params(**kw):
+    p = VsfParams()
+    lib().vsf_default_params(C.byref(p))
+    for k, v in kw.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """Owner of one vsf_ctx."""
+
+    def __init__(self, params):
+        self.params = params
+        self._h = C.c_void_p()
+        rc = lib().vsf_create(C.byref(params), C.byref(self._h))
+        if rc != VSF_OK:
+            self._h = None
+            raise VsfError(rc, "vsf_create failed (no GPU / bad parameters)")
+        self.streams = params.streams
+        self.width, self.height = params.width, params.height
+        self.capacity = params.capacity if params.capacity > 0 else params.max_features + 64
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vsf_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != VSF_OK:
+            raise VsfError(rc, lib().vsf_last_error(self._h).decode())
+
+    # ---- single-stream host API ----
+    def track(self, img, ids, xy, age, n):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        nn = C.c_int32(n)
+        st = VsfTrackStats()
+        self._chk(lib().vsf_track(self._h, _vp(img), w, h, w, _vp(ids), _vp(xy), _vp(age),
+                                  C.byref(nn), C.byref(st)))
+        return nn.value, (st.input, st.forward, st.backward, st.verified)
+
+    def track_pair(self, prev, cur, ids, xy, age, n):
+        prev = np.ascontiguousarray(prev, np.uint8)
+        cur = np.ascontiguousarray(cur, np.uint8)
+        h, w = cur.shape
+        nn = C.c_int32(n)
+        st = VsfTrackStats()
+        self._chk(lib().vsf_track_pair(self._h, _vp(prev), w, _vp(cur), w, w, h, _vp(ids), _vp(xy),
+                                       _vp(age), C.byref(nn), C.byref(st)))
+        return nn.value, (st.input, st.forward, st.backward, st.verified)
+
+    def detect(self, img, ids, xy, age, n, mask=None):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        nn = C.c_int32(n)
+        mptr, mstride = None, 0
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, np.uint8)
+            mptr, mstride = _vp(mask), mask.shape[1]
+        self._chk(lib().vsf_detect(self._h, _vp(img), w, h, w, mptr, mstride, _vp(ids), _vp(xy),
+                                   _vp(age), C.byref(nn), len(ids)))
+        return nn.value
+
+    def get_max_feature_index(self, stream=0):
+        v = C.c_uint64()
+        self._chk(lib().vsf_get_max_feature_index(self._h, stream, C.byref(v)))
+        return v.value
+
+    def set_max_feature_index(self, value, stream=0):
+        self._chk(lib().vsf_set_max_feature_index(self._h, stream, C.c_uint64(value)))
+
+    def reset_tracker(self):
+        self._chk(lib().vsf_reset_tracker(self._h))
+
+    # ---- batched device API (pointers are raw device addresses, e.g. torch tensor.data_ptr()) ----
+    def batch_track(self, d_frames, frame_stride, row_stride, stream=0):
+        self._chk(lib().vsf_batch_track(self._h, C.c_void_p(d_frames), C.c_int64(frame_stride),
+                                        row_stride, C.c_void_p(stream)))
+
+    def batch_detect(self, d_frames, frame_stride, row_stride, d_masks=0, mask_stride=0,
+                     mask_row_stride=0, stream=0):
+        self._chk(lib().vsf_batch_detect(self._h, C.c_void_p(d_frames), C.c_int64(frame_stride),
+                                         row_stride, C.c_void_p(d_masks), C.c_int64(mask_stride),
+                                         mask_row_stride, C.c_void_p(stream)))
+
+    def batch_step(self, d_frames, frame_stride, row_stride, stream=0):
+        self._chk(lib().vsf_batch_step(self._h, C.c_void_p(d_frames), C.c_int64(frame_stride),
+                                       row_stride, C.c_void_p(stream)))
+
+    def batch_upload(self, ids, xy, age, n, first=0):
+        count = len(n)
+        ids = np.ascontiguousarray(ids, np.uint64)
+        xy = np.ascontiguousarray(xy, np.float64)
+        age = np.ascontiguousarray(age, np.uint32)
+        n = np.ascontiguousarray(n, np.int32)
+        assert ids.shape == (count, self.capacity) and xy.shape == (count, self.capacity, 2)
+        self._chk(lib().vsf_batch_upload(self._h, first, count, _vp(ids), _vp(xy), _vp(age), _vp(n)))
+
+    def batch_download(self, first=0, count=None):
+        count = self.streams - first if count is None else count
+        ids = np.zeros((count, self.capacity), np.uint64)
+        xy = np.zeros((count, self.capacity, 2), np.float64)
+        age = np.zeros((count, self.capacity), np.uint32)
+        n = np.zeros(count, np.int32)
+        stats = np.zeros((count, 4), np.int32)
+        self._chk(lib().vsf_batch_download(self._h, first, count, _vp(ids), _vp(xy), _vp(age), _vp(n),
+                                           _vp(stats)))
+        return ids, xy, age, n, stats
+
+    def batch_device_tables(self):
+        p = [C.c_void_p() for _ in range(4)]
+        cap = C.c_int32()
+        self._chk(lib().vsf_batch_device_tables(self._h, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]),
+                                                C.byref(p[3]), C.byref(cap)))
+        return [x.value for x in p], cap.value
+
+    def batch_status(self):
+        st = np.zeros(self.streams, np.int32)
+        self._chk(lib().vsf_batch_status(self._h, _vp(st)))
+        return st
+
+    # ---- building blocks for parity tests ----
+    def debug_pyramid(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        dims = [(h, w)]
+        for _ in range(8):
+            hh, ww = dims[-1]
+            dims.append(((hh + 1) // 2, (ww + 1) // 2))
+        bufs = [np.zeros(d, np.uint8) for d in dims[:8]]
+        arr = (C.c_void_p * 8)(*[b.ctypes.data for b in bufs])
+        ml = C.c_int32()
+        self._chk(lib().vsf_debug_pyramid(self._h, _vp(img), w, h, w, arr, C.byref(ml)))
+        return [img] + bufs[1:ml.value + 1]
+
+    def debug_lk(self, prev, nxt, pts):
+        prev = np.ascontiguousarray(prev, np.uint8)
+        nxt = np.ascontiguousarray(nxt, np.uint8)
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        h, w = prev.shape
+        n = len(pts)
+        out = np.zeros((n, 2), np.float32)
+        st = np.zeros(n, np.uint8)
+        self._chk(lib().vsf_debug_lk(self._h, _vp(prev), _vp(nxt), w, h, _vp(pts), _vp(out), _vp(st), n))
+        return out, st
+
+    def debug_min_eig(self, img, cell):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.zeros(h * w, np.float32)
+        rect = (C.c_int32 * 4)()
+        self._chk(lib().vsf_debug_min_eig(self._h, _vp(img), w, h, w, cell, _vp(out), rect))
+        rx, ry, rw, rh = [int(v) for v in rect]
+        return out[:rw * rh].reshape(rh, rw).copy(), (rx, ry, rw, rh)
+
+    # ---- profiling ----
+    def profile_enable(self, on=True):
+        self._chk(lib().vsf_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self):
+        ms = (C.c_float * len(KERNEL_NAMES))()
+        cnt = (C.c_int32 * len(KERNEL_NAMES))()
+        self._chk(lib().vsf_profile_read(self._h, ms, cnt))
+        return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+
+class FeatureDatabase:
+    """FeaturePositionDatabase + FeatureAgeDatabase (ref: src/vslam/type_defines.hpp:95-99) as the
+    SoA image that crosses the C ABI."""
+
+    def __init__(self, capacity):
+        self.capacity = capacity
+        self.ids = np.zeros(capacity, np.uint64)
+        self.xy = np.zeros((capacity, 2), np.float64)
+        self.age = np.zeros(capacity, np.uint32)
+        self.n = 0
+
+    def set(self, ids, xy, age):
+        n = len(ids)
+        assert n <= self.capacity
+        self.ids[:n], self.xy[:n], self.age[:n] = ids, xy, age
+        self.n = n
+
+    def as_dict(self):
+        return {int(i): (float(p[0]), float(p[1]), int(a))
+                for i, p, a in zip(self.ids[:self.n], self.xy[:self.n], self.age[:self.n])}
+
+
+class FeatureDetectorShiTomasiBucketing:
+    """Mirror of vslam::feature::FeatureDetectorShiTomasiBucketing
+    (ref: FeatureDetectorShiTomasiBucketing.hpp:30-59): same ctor arguments, UpdateDetection."""
+
+    def __init__(self, division_number_row, division_number_col, max_feature_number,
+                 min_feature_distance, width, height, device_id=0, capacity=0):
+        p = default_params(grid_rows=division_number_row, grid_cols=division_number_col,
+                           max_features=max_feature_number, min_distance=min_feature_distance,
+                           width=width, height=height, device_id=device_id, capacity=capacity)
+        self.ctx = Context(p)
+
+    def UpdateDetection(self, db, current_image, mask_image=None):
+        db.n = self.ctx.detect(current_image, db.ids, db.xy, db.age, db.n, mask_image)
+
+    @property
+    def max_feature_index_(self):
+        return self.ctx.get_max_feature_index()
+
+
+class FeatureTrackerLucasKanade:
+    """Mirror of vslam::feature::FeatureTrackerLucasKanade
+    (ref: FeatureTrackerLucasKanade.hpp:17-48): same ctor arguments, 3- and 4-argument Track."""
+
+    def __init__(self, klt_max_iteration, klt_epsilon, klt_window_size, klt_max_level,
+                 backtrack_distance_threshold, width, height, device_id=0, capacity=1024):
+        p = default_params(klt_max_iter=klt_max_iteration, klt_eps=klt_epsilon,
+                           klt_win=klt_window_size, klt_max_level=klt_max_level,
+                           backtrack_thr=backtrack_distance_threshold, width=width, height=height,
+                           device_id=device_id, capacity=capacity)
+        self.ctx = Context(p)
+        self.last_stats = None
+
+    def Track(self, db, *images):
+        if len(images) == 1:
+            db.n, self.last_stats = self.ctx.track(images[0], db.ids, db.xy, db.age, db.n)
+        else:
+            db.n, self.last_stats = self.ctx.track_pair(images[0], images[1], db.ids, db.xy, db.age,
+                                                        db.n)

@@ -1,0 +1,891 @@
+// vsf_api.hip -- C ABI (include/vsf.h) over the HIP kernels in vsf_kernels.hpp.
+// Host side only orchestrates: allocation, geometry, kernel launches on the caller's HIP stream.
+// No CPU fallback exists; every numeric result comes from the gfx950 kernels.
+#include "../../include/vsf.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "vsf_kernels.hpp"
+
+using namespace vsf;
+
+namespace {
+
+struct PyrSet {            // levels >= 1 of `streams` pyramids
+  uint8_t* lv[MAXL] = {};  // lv[0] unused
+};
+
+struct FrameRef {  // level 0 of a pyramid
+  const uint8_t* ptr = nullptr;
+  long long sstride = 0;
+  int pitch = 0;
+};
+
+struct EvPair {
+  int kid;
+  hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct vsf_ctx {
+  vsf_params p;
+  int cap = 0;
+  int B = 0;
+  // pyramid geometry
+  int nlevels = 0;
+  int lw[MAXL], lh[MAXL];
+  // tracker state
+  PyrSet track_pyr[2];
+  FrameRef track_frame[2];
+  int cur = 0;
+  bool has_prev = false;
+  uint8_t* own_frame[2] = {};  // host-API staging of stream 0 (ping-pong: previous frame stays resident)
+  // stateless pair / debug buffers (single stream), allocated lazily
+  PyrSet pair_pyr[2];
+  uint8_t* pair_frame[2] = {};
+  bool pair_ready = false;
+  // detector frame / mask staging for the host API
+  uint8_t* det_frame = nullptr;
+  uint8_t* det_mask = nullptr;
+  // table
+  uint64_t* d_ids = nullptr;
+  double2* d_xy = nullptr;
+  uint32_t* d_age = nullptr;
+  int* d_n = nullptr;
+  float2* d_fwd = nullptr;
+  uint8_t* d_flags = nullptr;
+  int* d_stats = nullptr;
+  int* d_status = nullptr;
+  uint64_t* d_maxidx = nullptr;
+  // detector
+  int ncell = 0, grid_max = 0, lam_total = 0, cand_cap = 0, hash_size = 0;
+  int max_cw = 0, max_ch = 0;
+  int4* d_rects = nullptr;
+  float2* d_origin = nullptr;
+  int* d_lam_off = nullptr;
+  int* d_need = nullptr;
+  int* d_nact = nullptr;
+  unsigned int* d_cellmax = nullptr;
+  int* d_candcnt = nullptr;
+  unsigned long long* d_cand = nullptr;
+  float* d_lam = nullptr;
+  double2* d_selxy = nullptr;
+  int* d_selcnt = nullptr;
+  float k_side = 0.f, k_mid = 0.f;
+  // LK
+  LkParams lk;
+  LkSmem lks;
+  // profiling
+  bool prof = false;
+  std::vector<EvPair> ev_used;
+  std::vector<EvPair> ev_free;
+  char err[256] = {0};
+};
+
+namespace {
+
+int fail(vsf_ctx* c, int code, const char* fmt, ...) {
+  if (c) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(c->err, sizeof(c->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define HIPCHK(c, call)                                                                         \
+  do {                                                                                          \
+    hipError_t e_ = (call);                                                                     \
+    if (e_ != hipSuccess) return fail(c, VSF_E_HIP, "%s: %s", #call, hipGetErrorString(e_));    \
+  } while (0)
+
+template <typename T>
+int dalloc(vsf_ctx* c, T** p, size_t count) {
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T) ? count * sizeof(T) : 16));
+  return VSF_OK;
+}
+
+struct ProfScope {
+  vsf_ctx* c;
+  hipStream_t s;
+  EvPair e;
+  bool on;
+  ProfScope(vsf_ctx* c_, int kid, hipStream_t s_) : c(c_), s(s_), on(c_->prof) {
+    if (!on) return;
+    if (!c->ev_free.empty()) {
+      e = c->ev_free.back();
+      c->ev_free.pop_back();
+    } else {
+      if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) {
+        on = false;
+        return;
+      }
+    }
+    e.kid = kid;
+    (void)hipEventRecord(e.a, s);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e.b, s);
+    c->ev_used.push_back(e);
+  }
+};
+
+PyrView make_view(const vsf_ctx* c, const FrameRef& f, const PyrSet& ps) {
+  PyrView v;
+  memset(&v, 0, sizeof(v));
+  v.nlevels = c->nlevels;
+  for (int l = 0; l < c->nlevels; l++) {
+    v.w[l] = c->lw[l];
+    v.h[l] = c->lh[l];
+    if (l == 0) {
+      v.base[0] = f.ptr;
+      v.sstride[0] = f.sstride;
+      v.pitch[0] = f.pitch;
+    } else {
+      v.base[l] = ps.lv[l];
+      v.sstride[l] = (long long)c->lw[l] * c->lh[l];
+      v.pitch[l] = c->lw[l];
+    }
+  }
+  return v;
+}
+
+int alloc_pyr(vsf_ctx* c, PyrSet* ps, int streams) {
+  for (int l = 1; l < c->nlevels; l++) {
+    int rc = dalloc(c, &ps->lv[l], (size_t)streams * c->lw[l] * c->lh[l]);
+    if (rc) return rc;
+  }
+  return VSF_OK;
+}
+
+// cv::buildOpticalFlowPyramid levels >= 1 (level 0 is the frame itself)
+int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStream_t s) {
+  ProfScope prof(c, VSF_K_PYRAMID, s);
+  for (int l = 1; l < c->nlevels; l++) {
+    const uint8_t* src = (l == 1) ? f.ptr : ps.lv[l - 1];
+    const long long sst = (l == 1) ? f.sstride : (long long)c->lw[l - 1] * c->lh[l - 1];
+    const int sp = (l == 1) ? f.pitch : c->lw[l - 1];
+    dim3 grid((c->lw[l] + PD_TW - 1) / PD_TW, (c->lh[l] + PD_TH - 1) / PD_TH, streams);
+    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
+                       ps.lv[l], (long long)c->lw[l] * c->lh[l], c->lw[l], c->lw[l], c->lh[l]);
+  }
+  HIPCHK(c, hipGetLastError());
+  return VSF_OK;
+}
+
+int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hipStream_t s) {
+  ProfScope prof(c, VSF_K_LK, s);
+  dim3 grid(c->cap, streams);
+  if (c->lk.seglen <= 8)
+    hipLaunchKernelGGL(lk_fb_kernel<8>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, c->lk,
+                       c->d_fwd, c->d_flags);
+  else
+    hipLaunchKernelGGL(lk_fb_kernel<16>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, c->lk,
+                       c->d_fwd, c->d_flags);
+  HIPCHK(c, hipGetLastError());
+  return VSF_OK;
+}
+
+int launch_compact(vsf_ctx* c, int streams, hipStream_t s) {
+  ProfScope prof(c, VSF_K_COMPACT, s);
+  hipLaunchKernelGGL(compact_kernel, dim3(streams), dim3(256), 0, s, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap,
+                     c->d_fwd, c->d_flags, c->d_stats);
+  HIPCHK(c, hipGetLastError());
+  return VSF_OK;
+}
+
+GridView grid_view(const vsf_ctx* c) {
+  GridView g;
+  g.rects = c->d_rects;
+  g.origin = c->d_origin;
+  g.lam_off = c->d_lam_off;
+  g.ncell = c->ncell;
+  g.rows = c->p.grid_rows;
+  g.cols = c->p.grid_cols;
+  g.grid_max = c->grid_max;
+  g.lam_total = c->lam_total;
+  return g;
+}
+
+// Track on `streams` streams given the current frames (already on the device).
+int track_impl(vsf_ctx* c, const FrameRef& f, int streams, hipStream_t s) {
+  const int nxt = c->cur ^ 1;
+  int rc = build_pyramid(c, f, c->track_pyr[nxt], streams, s);
+  if (rc) return rc;
+  c->track_frame[nxt] = f;
+  if (c->has_prev) {  // ref: FeatureTrackerLucasKanade.cpp:29-32 -- first call only stores the frame
+    const PyrView P = make_view(c, c->track_frame[c->cur], c->track_pyr[c->cur]);
+    const PyrView C = make_view(c, f, c->track_pyr[nxt]);
+    rc = launch_lk_fb(c, P, C, streams, s);
+    if (rc) return rc;
+    rc = launch_compact(c, streams, s);
+    if (rc) return rc;
+  }
+  c->cur = nxt;
+  c->has_prev = true;
+  return VSF_OK;
+}
+
+int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long mask_sstride, int mask_pitch,
+                int streams, hipStream_t s) {
+  const GridView G = grid_view(c);
+  const int W = c->p.width, H = c->p.height;
+  {
+    ProfScope prof(c, VSF_K_OCCUPANCY, s);
+    const size_t sm = (size_t)(c->hash_size + c->ncell) * sizeof(int);
+    hipLaunchKernelGGL(occupancy_kernel, dim3(streams), dim3(256), sm, s, c->d_xy, c->d_n, c->cap, G, W, H,
+                       c->hash_size, c->d_need, c->d_nact, c->d_cellmax, c->d_candcnt);
+  }
+  const int tiles_x = (c->max_cw + SC_TW - 1) / SC_TW, tiles_y = (c->max_ch + SC_TH - 1) / SC_TH;
+  {
+    ProfScope prof(c, VSF_K_SCORE, s);
+    hipLaunchKernelGGL(score_kernel, dim3(tiles_x * tiles_y, c->ncell, streams), dim3(256), 0, s, f.ptr, f.sstride,
+                       f.pitch, W, H, masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, c->k_side, c->k_mid,
+                       c->d_lam, c->d_cellmax);
+  }
+  {
+    ProfScope prof(c, VSF_K_CANDIDATES, s);
+    hipLaunchKernelGGL(candidate_kernel, dim3(tiles_x * tiles_y, c->ncell, streams), dim3(256), 0, s, c->d_lam, G,
+                       c->d_nact, tiles_x, c->d_cellmax, c->p.quality_level, masks, mask_sstride, mask_pitch,
+                       c->d_cand, c->cand_cap, c->d_candcnt);
+  }
+  {
+    ProfScope prof(c, VSF_K_SELECT, s);
+    SelParams sp;
+    sp.min_dist = c->p.min_distance;
+    sp.quality = c->p.quality_level;
+    sp.cap = c->cap;
+    sp.cand_cap = c->cand_cap;
+    sp.sel_cap = c->grid_max > 0 ? c->grid_max : 1;
+    const size_t sm = (size_t)c->cand_cap * 8 + (size_t)sp.sel_cap * 12;
+    hipLaunchKernelGGL(select_kernel, dim3(c->ncell, streams), dim3(256), sm, s, c->d_lam, G, c->d_nact, c->d_need,
+                       c->d_cellmax, masks, mask_sstride, mask_pitch, c->d_cand, c->d_candcnt, sp, c->d_xy, c->d_n,
+                       c->d_selxy, c->d_selcnt);
+  }
+  {
+    ProfScope prof(c, VSF_K_APPEND, s);
+    const int sel_cap = c->grid_max > 0 ? c->grid_max : 1;
+    const size_t sm = (size_t)(c->ncell + 1 + c->ncell * sel_cap) * sizeof(int);
+    hipLaunchKernelGGL(append_kernel, dim3(streams), dim3(256), sm, s, G, c->d_nact, c->d_selxy, c->d_selcnt,
+                       sel_cap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, c->d_maxidx, c->d_status);
+  }
+  HIPCHK(c, hipGetLastError());
+  return VSF_OK;
+}
+
+// ref: FeatureDetectorShiTomasiBucketing.cpp:13-36 (GenerateGrid) and :144-149 (Rect2f -> Rect)
+void host_grid(int w, int h, int cols, int rows, std::vector<int4>& rects, std::vector<float2>& origin) {
+  const double dx = (double)w / (double)cols, dy = (double)h / (double)rows;
+  for (int x = 0; x < cols; x++)
+    for (int y = 0; y < rows; y++) {
+      const float lx = (float)(x * dx), ly = (float)(y * dy);
+      const float rx = lx + (float)dx, ry = ly + (float)dy;
+      const float wf = rx - lx, hf = ry - ly;
+      int4 r;
+      r.x = (int)lrintf(lx);
+      r.y = (int)lrintf(ly);
+      r.z = (int)lrintf(wf);
+      r.w = (int)lrintf(hf);
+      rects.push_back(r);
+      float2 o;
+      o.x = lx;
+      o.y = ly;
+      origin.push_back(o);
+    }
+}
+
+int upload_frame(vsf_ctx* c, uint8_t* dst, const uint8_t* img, int w, int h, int stride) {
+  HIPCHK(c, hipMemcpy2D(dst, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice));
+  return VSF_OK;
+}
+
+int upload_table0(vsf_ctx* c, const uint64_t* ids, const double* xy, const uint32_t* age, int n) {
+  if (n < 0 || n > c->cap) return fail(c, VSF_E_CAPACITY, "table of %d entries exceeds capacity %d", n, c->cap);
+  if (n > 0) {
+    HIPCHK(c, hipMemcpy(c->d_ids, ids, (size_t)n * 8, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_xy, xy, (size_t)n * 16, hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_age, age, (size_t)n * 4, hipMemcpyHostToDevice));
+  }
+  HIPCHK(c, hipMemcpy(c->d_n, &n, 4, hipMemcpyHostToDevice));
+  return VSF_OK;
+}
+
+int download_table0(vsf_ctx* c, uint64_t* ids, double* xy, uint32_t* age, int* n, int capacity) {
+  int m = 0;
+  HIPCHK(c, hipMemcpy(&m, c->d_n, 4, hipMemcpyDeviceToHost));
+  if (m > capacity) return fail(c, VSF_E_CAPACITY, "result of %d entries exceeds caller capacity %d", m, capacity);
+  if (m > 0) {
+    HIPCHK(c, hipMemcpy(ids, c->d_ids, (size_t)m * 8, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(xy, c->d_xy, (size_t)m * 16, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(age, c->d_age, (size_t)m * 4, hipMemcpyDeviceToHost));
+  }
+  *n = m;
+  return VSF_OK;
+}
+
+int check_geom(vsf_ctx* c, int w, int h, int stride) {
+  if (w != c->p.width || h != c->p.height)
+    return fail(c, VSF_E_GEOMETRY, "frame %dx%d does not match the context's %dx%d", w, h, c->p.width, c->p.height);
+  if (stride < w) return fail(c, VSF_E_INVALID, "stride %d < width %d", stride, w);
+  return VSF_OK;
+}
+
+int ensure_pair(vsf_ctx* c) {
+  if (c->pair_ready) return VSF_OK;
+  const size_t fs = (size_t)c->p.width * c->p.height;
+  for (int i = 0; i < 2; i++) {
+    int rc = dalloc(c, &c->pair_frame[i], fs);
+    if (rc) return rc;
+    rc = alloc_pyr(c, &c->pair_pyr[i], 1);
+    if (rc) return rc;
+  }
+  c->pair_ready = true;
+  return VSF_OK;
+}
+
+FrameRef own_ref(const vsf_ctx* c, const uint8_t* p) {
+  FrameRef f;
+  f.ptr = p;
+  f.sstride = (long long)c->p.width * c->p.height;
+  f.pitch = c->p.width;
+  return f;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* vsf_version(void) { return "vsf-hip 0.1 (gfx950)"; }
+
+void vsf_default_params(vsf_params* p) {
+  memset(p, 0, sizeof(*p));
+  p->grid_rows = 4;
+  p->grid_cols = 4;
+  p->max_features = 300;
+  p->min_distance = 2.0;
+  p->quality_level = 0.1;
+  p->block_size = 3;
+  p->klt_max_iter = 30;
+  p->klt_eps = 0.01;
+  p->klt_win = 21;
+  p->klt_max_level = 3;
+  p->min_eig_thr = 1e-4;
+  p->backtrack_thr = 1.0;
+  p->width = 752;
+  p->height = 480;
+  p->streams = 1;
+  p->capacity = 0;
+  p->device_id = 0;
+}
+
+const char* vsf_last_error(const vsf_ctx* ctx) { return ctx ? ctx->err : "null context"; }
+
+void vsf_destroy(vsf_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->p.device_id);
+  (void)hipDeviceSynchronize();
+  for (int i = 0; i < 2; i++) {
+    for (int l = 0; l < MAXL; l++) {
+      if (c->track_pyr[i].lv[l]) (void)hipFree(c->track_pyr[i].lv[l]);
+      if (c->pair_pyr[i].lv[l]) (void)hipFree(c->pair_pyr[i].lv[l]);
+    }
+    if (c->own_frame[i]) (void)hipFree(c->own_frame[i]);
+    if (c->pair_frame[i]) (void)hipFree(c->pair_frame[i]);
+  }
+  void* bufs[] = {c->det_frame, c->det_mask, c->d_ids,    c->d_xy,      c->d_age,   c->d_n,      c->d_fwd,
+                  c->d_flags,   c->d_stats,  c->d_status, c->d_maxidx,  c->d_rects, c->d_origin, c->d_lam_off,
+                  c->d_need,    c->d_nact,   c->d_cellmax, c->d_candcnt, c->d_cand,  c->d_lam,    c->d_selxy,
+                  c->d_selcnt};
+  for (void* b : bufs)
+    if (b) (void)hipFree(b);
+  for (auto& e : c->ev_used) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  for (auto& e : c->ev_free) {
+    (void)hipEventDestroy(e.a);
+    (void)hipEventDestroy(e.b);
+  }
+  delete c;
+}
+
+int vsf_create(const vsf_params* p, vsf_ctx** out) {
+  if (!p || !out) return VSF_E_INVALID;
+  *out = nullptr;
+  if (p->width <= 0 || p->height <= 0 || p->streams < 1 || p->streams > 65535) return VSF_E_INVALID;
+  if (p->klt_win < 3 || p->klt_win > MAX_WIN || p->klt_max_level < 0 || p->klt_max_level >= MAXL)
+    return VSF_E_INVALID;
+  if (p->width <= p->klt_win || p->height <= p->klt_win) return VSF_E_INVALID;
+  if (p->grid_rows < 1 || p->grid_cols < 1 || p->max_features < 0 || p->block_size != 3) return VSF_E_INVALID;
+  if (!(p->min_distance >= 0.0) || !(p->quality_level >= 0.0)) return VSF_E_INVALID;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device_id < 0 || p->device_id >= ndev)
+    return VSF_E_HIP;  // no GPU: fail loudly, there is no CPU path
+  if (hipSetDevice(p->device_id) != hipSuccess) return VSF_E_HIP;
+
+  vsf_ctx* c = new (std::nothrow) vsf_ctx();
+  if (!c) return VSF_E_NOMEM;
+  c->p = *p;
+  c->B = p->streams;
+  c->cap = p->capacity > 0 ? p->capacity : p->max_features + 64;
+  const int B = c->B;
+
+  // pyramid geometry: cv::buildOpticalFlowPyramid stops when the NEXT level would be <= the window
+  {
+    int w = p->width, h = p->height, l = 0;
+    for (;; l++) {
+      c->lw[l] = w;
+      c->lh[l] = h;
+      w = (w + 1) / 2;
+      h = (h + 1) / 2;
+      if (l == p->klt_max_level || w <= p->klt_win || h <= p->klt_win) break;
+    }
+    c->nlevels = l + 1;
+  }
+  // LK lane mapping
+  {
+    LkParams& k = c->lk;
+    k.win = p->klt_win;
+    k.nseg = 64 / k.win;
+    k.seglen = (k.win + k.nseg - 1) / k.nseg;
+    int mc = p->klt_max_iter;  // cv: TermCriteria clamp
+    mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);
+    k.max_count = mc;
+    double e = p->klt_eps;
+    e = e < 0. ? 0. : (e > 10. ? 10. : e);
+    k.eps2 = e * e;
+    k.min_eig_thr = p->min_eig_thr;
+    k.backtrack_thr = p->backtrack_thr;
+    k.jmargin = 3;
+    c->lks = lk_smem_layout(k.win, k.jmargin);
+  }
+  // detector grid
+  std::vector<int4> rects;
+  std::vector<float2> origin;
+  host_grid(p->width, p->height, p->grid_cols, p->grid_rows, rects, origin);
+  c->ncell = (int)rects.size();
+  c->grid_max = p->max_features / (p->grid_rows * p->grid_cols);  // Q3
+  std::vector<int> lam_off(c->ncell + 1, 0);
+  for (int i = 0; i < c->ncell; i++) {
+    const int4 r = rects[i];
+    if (r.x < 0 || r.y < 0 || r.z < 0 || r.w < 0 || r.x + r.z > p->width || r.y + r.w > p->height) {
+      delete c;
+      return VSF_E_GEOMETRY;
+    }
+    lam_off[i + 1] = lam_off[i] + r.z * r.w;
+    if (r.z > c->max_cw) c->max_cw = r.z;
+    if (r.w > c->max_ch) c->max_ch = r.w;
+  }
+  c->lam_total = lam_off[c->ncell];
+  if (c->max_cw < 1) c->max_cw = 1;
+  if (c->max_ch < 1) c->max_ch = 1;
+  if (c->grid_max > 8192) {
+    delete c;
+    return VSF_E_INVALID;
+  }
+  c->cand_cap = 2048;
+  c->hash_size = 64;
+  while (c->hash_size < 2 * c->cap) c->hash_size <<= 1;
+  if ((size_t)(c->hash_size + c->ncell) * 4 > 150 * 1024) {
+    delete c;
+    return VSF_E_INVALID;
+  }
+  {
+    const double scale = 1.0 / ((double)(1 << 2) * p->block_size * 255.0);  // cv: cornerEigenValsVecs
+    c->k_side = (float)(1.0 * scale);
+    c->k_mid = (float)(2.0 * scale);
+  }
+
+  int rc = VSF_OK;
+#define A(expr)                 \
+  do {                          \
+    if (!rc) rc = (expr);       \
+  } while (0)
+  for (int i = 0; i < 2; i++) A(alloc_pyr(c, &c->track_pyr[i], B));
+  const size_t fs = (size_t)p->width * p->height;
+  A(dalloc(c, &c->own_frame[0], fs));
+  A(dalloc(c, &c->own_frame[1], fs));
+  A(dalloc(c, &c->det_frame, fs));
+  A(dalloc(c, &c->det_mask, fs));
+  const size_t T = (size_t)B * c->cap;
+  A(dalloc(c, &c->d_ids, T));
+  A(dalloc(c, &c->d_xy, T));
+  A(dalloc(c, &c->d_age, T));
+  A(dalloc(c, &c->d_n, (size_t)B));
+  A(dalloc(c, &c->d_fwd, T));
+  A(dalloc(c, &c->d_flags, T));
+  A(dalloc(c, &c->d_stats, (size_t)B * 4));
+  A(dalloc(c, &c->d_status, (size_t)B));
+  A(dalloc(c, &c->d_maxidx, (size_t)B));
+  A(dalloc(c, &c->d_rects, (size_t)c->ncell));
+  A(dalloc(c, &c->d_origin, (size_t)c->ncell));
+  A(dalloc(c, &c->d_lam_off, (size_t)c->ncell + 1));
+  const size_t BC = (size_t)B * c->ncell;
+  A(dalloc(c, &c->d_need, BC));
+  A(dalloc(c, &c->d_nact, (size_t)B));
+  A(dalloc(c, &c->d_cellmax, BC));
+  A(dalloc(c, &c->d_candcnt, BC));
+  A(dalloc(c, &c->d_cand, BC * c->cand_cap));
+  A(dalloc(c, &c->d_lam, (size_t)B * c->lam_total));
+  A(dalloc(c, &c->d_selxy, BC * (size_t)(c->grid_max > 0 ? c->grid_max : 1)));
+  A(dalloc(c, &c->d_selcnt, BC));
+#undef A
+  if (!rc) {
+    hipError_t e = hipSuccess;
+    auto acc = [&](hipError_t x) {
+      if (e == hipSuccess) e = x;
+    };
+    acc(hipMemset(c->d_n, 0, (size_t)B * 4));
+    acc(hipMemset(c->d_stats, 0, (size_t)B * 16));
+    acc(hipMemset(c->d_status, 0, (size_t)B * 4));
+    acc(hipMemset(c->d_maxidx, 0, (size_t)B * 8));  // ref ctor: max_feature_index_(0)
+    acc(hipMemset(c->d_flags, 0, T));
+    acc(hipMemcpy(c->d_rects, rects.data(), rects.size() * sizeof(int4), hipMemcpyHostToDevice));
+    acc(hipMemcpy(c->d_origin, origin.data(), origin.size() * sizeof(float2), hipMemcpyHostToDevice));
+    acc(hipMemcpy(c->d_lam_off, lam_off.data(), lam_off.size() * sizeof(int), hipMemcpyHostToDevice));
+    // dynamic LDS above the default limit needs an explicit opt-in
+    const int occ_sm = (c->hash_size + c->ncell) * 4;
+    if (occ_sm > 48 * 1024)
+      acc(hipFuncSetAttribute(reinterpret_cast<const void*>(occupancy_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, occ_sm));
+    const int sel_sm = c->cand_cap * 8 + (c->grid_max > 0 ? c->grid_max : 1) * 12;
+    if (sel_sm > 48 * 1024)
+      acc(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, sel_sm));
+    const int app_sm = (c->ncell + 1 + c->ncell * (c->grid_max > 0 ? c->grid_max : 1)) * 4;
+    if (app_sm > 48 * 1024)
+      acc(hipFuncSetAttribute(reinterpret_cast<const void*>(append_kernel),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, app_sm));
+    if (e != hipSuccess) rc = VSF_E_HIP;
+  }
+  if (rc) {
+    vsf_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return VSF_OK;
+}
+
+int vsf_reset_tracker(vsf_ctx* c) {
+  if (!c) return VSF_E_INVALID;
+  c->has_prev = false;
+  return VSF_OK;
+}
+
+int vsf_get_max_feature_index(vsf_ctx* c, int32_t stream, uint64_t* out) {
+  if (!c || !out || stream < 0 || stream >= c->B) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  HIPCHK(c, hipMemcpy(out, c->d_maxidx + stream, 8, hipMemcpyDeviceToHost));
+  return VSF_OK;
+}
+
+int vsf_set_max_feature_index(vsf_ctx* c, int32_t stream, uint64_t value) {
+  if (!c || stream < 0 || stream >= c->B) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  HIPCHK(c, hipMemcpy(c->d_maxidx + stream, &value, 8, hipMemcpyHostToDevice));
+  return VSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-stream host API
+// ------------------------------------------------------------------------------------------------
+int vsf_track(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, uint64_t* ids, double* xy,
+              uint32_t* age, int32_t* n_inout, vsf_track_stats* stats) {
+  if (!c || !img || !n_inout) return VSF_E_INVALID;
+  int rc = check_geom(c, w, h, stride);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  const int n = *n_inout;
+  if (n > 0 && (!ids || !xy || !age)) return VSF_E_INVALID;
+  uint8_t* slot = c->own_frame[c->cur ^ 1];
+  rc = upload_frame(c, slot, img, w, h, stride);
+  if (rc) return rc;
+  const bool first = !c->has_prev;
+  rc = upload_table0(c, ids, xy, age, n);
+  if (rc) return rc;
+  rc = track_impl(c, own_ref(c, slot), 1, nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(nullptr));
+  if (first) {  // :29-32 table untouched
+    if (stats) stats->input = stats->forward = stats->backward = stats->verified = n;
+    return VSF_OK;
+  }
+  rc = download_table0(c, ids, xy, age, n_inout, n);
+  if (rc) return rc;
+  if (stats) HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(*stats), hipMemcpyDeviceToHost));
+  return VSF_OK;
+}
+
+int vsf_track_pair(vsf_ctx* c, const uint8_t* prev, int32_t prev_stride, const uint8_t* cur, int32_t cur_stride,
+                   int32_t w, int32_t h, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout,
+                   vsf_track_stats* stats) {
+  if (!c || !prev || !cur || !n_inout) return VSF_E_INVALID;
+  int rc = check_geom(c, w, h, prev_stride);
+  if (!rc) rc = check_geom(c, w, h, cur_stride);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  const int n = *n_inout;
+  if (n > 0 && (!ids || !xy || !age)) return VSF_E_INVALID;
+  rc = ensure_pair(c);
+  if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, prev_stride);
+  if (!rc) rc = upload_frame(c, c->pair_frame[1], cur, w, h, cur_stride);
+  if (!rc) rc = upload_table0(c, ids, xy, age, n);
+  if (rc) return rc;
+  const FrameRef fp = own_ref(c, c->pair_frame[0]), fc = own_ref(c, c->pair_frame[1]);
+  rc = build_pyramid(c, fp, c->pair_pyr[0], 1, nullptr);
+  if (!rc) rc = build_pyramid(c, fc, c->pair_pyr[1], 1, nullptr);
+  if (!rc) rc = launch_lk_fb(c, make_view(c, fp, c->pair_pyr[0]), make_view(c, fc, c->pair_pyr[1]), 1, nullptr);
+  if (!rc) rc = launch_compact(c, 1, nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(nullptr));
+  rc = download_table0(c, ids, xy, age, n_inout, n);
+  if (rc) return rc;
+  if (stats) HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(*stats), hipMemcpyDeviceToHost));
+  return VSF_OK;
+}
+
+int vsf_detect(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, const uint8_t* mask,
+               int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout, int32_t capacity) {
+  if (!c || !img || !n_inout || !ids || !xy || !age) return VSF_E_INVALID;
+  int rc = check_geom(c, w, h, stride);
+  if (rc) return rc;
+  if (mask && mask_stride < w) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  rc = upload_frame(c, c->det_frame, img, w, h, stride);
+  if (!rc && mask) rc = upload_frame(c, c->det_mask, mask, w, h, mask_stride);
+  if (!rc) rc = upload_table0(c, ids, xy, age, *n_inout);
+  if (rc) return rc;
+  int zero = 0;
+  HIPCHK(c, hipMemcpy(c->d_status, &zero, 4, hipMemcpyHostToDevice));
+  rc = detect_impl(c, own_ref(c, c->det_frame), mask ? c->det_mask : nullptr, (long long)w * h, w, 1, nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(nullptr));
+  int st = 0;
+  HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
+  rc = download_table0(c, ids, xy, age, n_inout, capacity);
+  if (rc) return rc;
+  if (st) return fail(c, st, "feature table capacity %d exhausted during detection", c->cap);
+  return VSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batched device-resident API
+// ------------------------------------------------------------------------------------------------
+int vsf_batch_track(vsf_ctx* c, const uint8_t* d_frames, int64_t frame_stride_bytes, int32_t row_stride,
+                    void* hip_stream) {
+  if (!c || !d_frames || row_stride < c->p.width) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  FrameRef f;
+  f.ptr = d_frames;
+  f.sstride = frame_stride_bytes;
+  f.pitch = row_stride;
+  return track_impl(c, f, c->B, reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int vsf_batch_detect(vsf_ctx* c, const uint8_t* d_frames, int64_t frame_stride_bytes, int32_t row_stride,
+                     const uint8_t* d_masks, int64_t mask_stride_bytes, int32_t mask_row_stride, void* hip_stream) {
+  if (!c || !d_frames || row_stride < c->p.width) return VSF_E_INVALID;
+  if (d_masks && mask_row_stride < c->p.width) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  FrameRef f;
+  f.ptr = d_frames;
+  f.sstride = frame_stride_bytes;
+  f.pitch = row_stride;
+  return detect_impl(c, f, d_masks, mask_stride_bytes, mask_row_stride, c->B,
+                     reinterpret_cast<hipStream_t>(hip_stream));
+}
+
+int vsf_batch_step(vsf_ctx* c, const uint8_t* d_frames, int64_t frame_stride_bytes, int32_t row_stride,
+                   void* hip_stream) {
+  int rc = vsf_batch_track(c, d_frames, frame_stride_bytes, row_stride, hip_stream);
+  if (rc) return rc;
+  return vsf_batch_detect(c, d_frames, frame_stride_bytes, row_stride, nullptr, 0, 0, hip_stream);
+}
+
+int vsf_batch_upload(vsf_ctx* c, int32_t first, int32_t count, const uint64_t* ids, const double* xy,
+                     const uint32_t* age, const int32_t* n) {
+  if (!c || first < 0 || count < 0 || first + count > c->B || !ids || !xy || !age || !n) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  for (int i = 0; i < count; i++)
+    if (n[i] < 0 || n[i] > c->cap) return fail(c, VSF_E_CAPACITY, "stream %d: n=%d exceeds capacity", first + i, n[i]);
+  const size_t o = (size_t)first * c->cap, T = (size_t)count * c->cap;
+  HIPCHK(c, hipMemcpy(c->d_ids + o, ids, T * 8, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_xy + o, xy, T * 16, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_age + o, age, T * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemcpy(c->d_n + first, n, (size_t)count * 4, hipMemcpyHostToDevice));
+  return VSF_OK;
+}
+
+int vsf_batch_download(vsf_ctx* c, int32_t first, int32_t count, uint64_t* ids, double* xy, uint32_t* age,
+                       int32_t* n, vsf_track_stats* stats) {
+  if (!c || first < 0 || count < 0 || first + count > c->B || !ids || !xy || !age || !n) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  HIPCHK(c, hipDeviceSynchronize());
+  const size_t o = (size_t)first * c->cap, T = (size_t)count * c->cap;
+  HIPCHK(c, hipMemcpy(ids, c->d_ids + o, T * 8, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(xy, c->d_xy + o, T * 16, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(age, c->d_age + o, T * 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(n, c->d_n + first, (size_t)count * 4, hipMemcpyDeviceToHost));
+  if (stats) HIPCHK(c, hipMemcpy(stats, c->d_stats + (size_t)first * 4, (size_t)count * 16, hipMemcpyDeviceToHost));
+  return VSF_OK;
+}
+
+int vsf_batch_device_tables(vsf_ctx* c, void** ids, void** xy, void** age, void** n, int32_t* capacity) {
+  if (!c) return VSF_E_INVALID;
+  if (ids) *ids = c->d_ids;
+  if (xy) *xy = c->d_xy;
+  if (age) *age = c->d_age;
+  if (n) *n = c->d_n;
+  if (capacity) *capacity = c->cap;
+  return VSF_OK;
+}
+
+int vsf_batch_status(vsf_ctx* c, int32_t* status) {
+  if (!c || !status) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  HIPCHK(c, hipDeviceSynchronize());
+  HIPCHK(c, hipMemcpy(status, c->d_status, (size_t)c->B * 4, hipMemcpyDeviceToHost));
+  return VSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// building blocks for parity tests
+// ------------------------------------------------------------------------------------------------
+int vsf_debug_pyramid(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, uint8_t** out_levels,
+                      int32_t* max_level_out) {
+  if (!c || !img || !out_levels || !max_level_out) return VSF_E_INVALID;
+  int rc = check_geom(c, w, h, stride);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  rc = ensure_pair(c);
+  if (!rc) rc = upload_frame(c, c->pair_frame[0], img, w, h, stride);
+  if (!rc) rc = build_pyramid(c, own_ref(c, c->pair_frame[0]), c->pair_pyr[0], 1, nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(nullptr));
+  for (int l = 1; l < c->nlevels; l++)
+    if (out_levels[l])
+      HIPCHK(c, hipMemcpy(out_levels[l], c->pair_pyr[0].lv[l], (size_t)c->lw[l] * c->lh[l], hipMemcpyDeviceToHost));
+  *max_level_out = c->nlevels - 1;
+  return VSF_OK;
+}
+
+int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w, int32_t h, const float* prev_pts,
+                 float* next_pts, uint8_t* status, int32_t n) {
+  if (!c || !prev || !next || n < 0) return VSF_E_INVALID;
+  if (n == 0) return VSF_OK;
+  if (!prev_pts || !next_pts || !status) return VSF_E_INVALID;
+  int rc = check_geom(c, w, h, w);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  rc = ensure_pair(c);
+  if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, w);
+  if (!rc) rc = upload_frame(c, c->pair_frame[1], next, w, h, w);
+  if (rc) return rc;
+  float2 *d_in = nullptr, *d_out = nullptr;
+  uint8_t* d_st = nullptr;
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)n * 8));
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 8));
+  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_st), (size_t)n));
+  HIPCHK(c, hipMemcpy(d_in, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice));
+  const FrameRef fp = own_ref(c, c->pair_frame[0]), fc = own_ref(c, c->pair_frame[1]);
+  rc = build_pyramid(c, fp, c->pair_pyr[0], 1, nullptr);
+  if (!rc) rc = build_pyramid(c, fc, c->pair_pyr[1], 1, nullptr);
+  if (!rc) {
+    const PyrView P = make_view(c, fp, c->pair_pyr[0]), C = make_view(c, fc, c->pair_pyr[1]);
+    if (c->lk.seglen <= 8)
+      hipLaunchKernelGGL(lk_points_kernel<8>, dim3(n), dim3(64), c->lks.total, nullptr, P, C, d_in, n, c->lk, d_out,
+                         d_st);
+    else
+      hipLaunchKernelGGL(lk_points_kernel<16>, dim3(n), dim3(64), c->lks.total, nullptr, P, C, d_in, n, c->lk,
+                         d_out, d_st);
+    if (hipGetLastError() != hipSuccess) rc = VSF_E_HIP;
+  }
+  if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = VSF_E_HIP;
+  if (!rc && hipMemcpy(next_pts, d_out, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
+  if (!rc && hipMemcpy(status, d_st, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
+  (void)hipFree(d_in);
+  (void)hipFree(d_out);
+  (void)hipFree(d_st);
+  if (rc == VSF_E_HIP) return fail(c, rc, "vsf_debug_lk: HIP failure");
+  return rc;
+}
+
+int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t cell,
+                      float* out, int32_t* rect) {
+  if (!c || !img || !out || cell < 0 || cell >= c->ncell) return VSF_E_INVALID;
+  int rc = check_geom(c, w, h, stride);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  rc = upload_frame(c, c->det_frame, img, w, h, stride);
+  if (rc) return rc;
+  // all cells active: run occupancy on an empty table, then force n_active = ncell
+  int zero = 0;
+  int saved_n = 0;
+  HIPCHK(c, hipMemcpy(&saved_n, c->d_n, 4, hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(c->d_n, &zero, 4, hipMemcpyHostToDevice));
+  const GridView G = grid_view(c);
+  const size_t sm = (size_t)(c->hash_size + c->ncell) * sizeof(int);
+  hipLaunchKernelGGL(occupancy_kernel, dim3(1), dim3(256), sm, nullptr, c->d_xy, c->d_n, c->cap, G, w, h,
+                     c->hash_size, c->d_need, c->d_nact, c->d_cellmax, c->d_candcnt);
+  HIPCHK(c, hipMemcpy(c->d_nact, &c->ncell, 4, hipMemcpyHostToDevice));
+  const int tiles_x = (c->max_cw + SC_TW - 1) / SC_TW, tiles_y = (c->max_ch + SC_TH - 1) / SC_TH;
+  const FrameRef f = own_ref(c, c->det_frame);
+  hipLaunchKernelGGL(score_kernel, dim3(tiles_x * tiles_y, c->ncell, 1), dim3(256), 0, nullptr, f.ptr, f.sstride,
+                     f.pitch, w, h, (const uint8_t*)nullptr, 0ll, 0, G, c->d_nact, tiles_x, c->k_side, c->k_mid,
+                     c->d_lam, c->d_cellmax);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipStreamSynchronize(nullptr));
+  HIPCHK(c, hipMemcpy(c->d_n, &saved_n, 4, hipMemcpyHostToDevice));
+  std::vector<int4> rects(c->ncell);
+  std::vector<int> off(c->ncell + 1);
+  HIPCHK(c, hipMemcpy(rects.data(), c->d_rects, rects.size() * sizeof(int4), hipMemcpyDeviceToHost));
+  HIPCHK(c, hipMemcpy(off.data(), c->d_lam_off, off.size() * 4, hipMemcpyDeviceToHost));
+  const int4 r = rects[cell];
+  HIPCHK(c, hipMemcpy(out, c->d_lam + off[cell], (size_t)r.z * r.w * 4, hipMemcpyDeviceToHost));
+  if (rect) {
+    rect[0] = r.x;
+    rect[1] = r.y;
+    rect[2] = r.z;
+    rect[3] = r.w;
+  }
+  return VSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// profiling
+// ------------------------------------------------------------------------------------------------
+int vsf_profile_enable(vsf_ctx* c, int32_t on) {
+  if (!c) return VSF_E_INVALID;
+  c->prof = on != 0;
+  return VSF_OK;
+}
+
+int vsf_profile_read(vsf_ctx* c, float* total_ms, int32_t* launches) {
+  if (!c || !total_ms || !launches) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  HIPCHK(c, hipDeviceSynchronize());
+  for (int k = 0; k < VSF_K_COUNT; k++) {
+    total_ms[k] = 0.f;
+    launches[k] = 0;
+  }
+  for (auto& e : c->ev_used) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) {
+      total_ms[e.kid] += ms;
+      launches[e.kid] += 1;
+    }
+    c->ev_free.push_back(e);
+  }
+  c->ev_used.clear();
+  return VSF_OK;
+}
+
+}  // extern "C"

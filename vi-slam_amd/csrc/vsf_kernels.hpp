@@ -1,0 +1,901 @@
+// vsf_kernels.hpp -- hand-written HIP kernels (gfx950 / CDNA4, wave64) for the vision-frontend hot path.
+//
+// Algorithms follow SURVEY.md Appendix A (OpenCV 3.4 semantics the reference relies on) and the
+// wrapper logic of the reference (file:line citations at each kernel).  Integer stages are exact;
+// float stages are written so that, compiled with -ffp-contract=off, every expression is evaluated
+// in the order the CPU oracle uses (oracle/vsf_oracle.c), which makes detector results bit-exact.
+//
+// Layout in HBM (per context, B = streams):
+//   frames      : caller's 8-bit frames, frame s at base + s*frame_stride, rows row_stride apart
+//   pyramid     : levels >= 1, level l as [B][h_l][w_l] u8 (pitch = w_l), two sets (prev / cur)
+//   table       : ids [B][cap] u64, xy [B][cap] double2, age [B][cap] u32, n [B] i32
+//   lambda map  : per stream, per grid cell, min-eigenvalue map f32 [cell_h][cell_w]
+//   candidates  : per stream, per cell, up to cand_cap 64-bit keys (lambda bits << 32 | raster idx)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vsf {
+
+constexpr int MAXL = 8;      // pyramid levels supported (klt_max_level <= 7)
+constexpr int MAX_WIN = 32;  // LK window side supported
+constexpr int W_BITS = 14;
+
+struct PyrView {
+  const uint8_t* base[MAXL];   // level l of stream 0
+  long long sstride[MAXL];     // bytes between consecutive streams at level l
+  int pitch[MAXL], w[MAXL], h[MAXL];
+  int nlevels;                 // effective maxLevel + 1
+};
+
+struct LkParams {
+  int win;        // window side
+  int nseg;       // segments per window row (64 / win)
+  int seglen;     // pixels per lane
+  int max_count;  // clamped iteration count
+  double eps2;    // clamped eps, squared
+  double min_eig_thr;
+  double backtrack_thr;
+  int jmargin;    // extra margin staged around the J window
+};
+
+// cv: borderInterpolate(p, len, BORDER_REFLECT_101), one reflection, then clamped for memory safety
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (p < 0) p = -p;
+  if (p >= len) p = 2 * len - 2 - p;
+  return min(max(p, 0), len - 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pyramid: cv::pyrDown, 8-bit, [1 4 6 4 1]^2, (v+128)>>8, REFLECT_101.
+// One block = 64x16 output pixels of one stream.  The (131 x 35) source tile is staged in LDS with
+// coalesced row reads, filtered horizontally into LDS (int16), then vertically.
+// ------------------------------------------------------------------------------------------------
+constexpr int PD_TW = 64, PD_TH = 16;
+constexpr int PD_SW = 2 * PD_TW + 3, PD_SH = 2 * PD_TH + 3;
+constexpr int PD_SP = 136;  // LDS pitch of the source tile
+
+__global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict__ src, long long src_sstride,
+                                                       int src_pitch, int sw, int sh,
+                                                       uint8_t* __restrict__ dst, long long dst_sstride,
+                                                       int dst_pitch, int dw, int dh) {
+  __shared__ uint8_t s_src[PD_SH * PD_SP];
+  __shared__ uint16_t s_h[PD_SH * PD_TW];
+  const int stream = blockIdx.z;
+  const uint8_t* S = src + (long long)stream * src_sstride;
+  uint8_t* D = dst + (long long)stream * dst_sstride;
+  const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+  const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
+  for (int i = threadIdx.x; i < PD_SH * PD_SW; i += 256) {
+    const int y = i / PD_SW, x = i - y * PD_SW;
+    const int gy = reflect101(sy0 + y, sh), gx = reflect101(sx0 + x, sw);
+    s_src[y * PD_SP + x] = S[(long long)gy * src_pitch + gx];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD_SH * PD_TW; i += 256) {
+    const int y = i / PD_TW, x = i - y * PD_TW;
+    const uint8_t* r = s_src + y * PD_SP + 2 * x;
+    s_h[i] = (uint16_t)(r[0] + 4 * r[1] + 6 * r[2] + 4 * r[3] + r[4]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD_TH * PD_TW; i += 256) {
+    const int y = i / PD_TW, x = i - y * PD_TW;
+    const int gx = ox + x, gy = oy + y;
+    if (gx < dw && gy < dh) {
+      const uint16_t* c = s_h + (2 * y) * PD_TW + x;
+      const int v = c[0] + 4 * c[PD_TW] + 6 * c[2 * PD_TW] + 4 * c[3 * PD_TW] + c[4 * PD_TW];
+      D[(long long)gy * dst_pitch + gx] = (uint8_t)((v + 128) >> 8);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pyramidal LK (cv::calcOpticalFlowPyrLK scalar semantics), one wavefront per
+// feature.  Lane l owns window row r = l / nseg and the seglen consecutive pixels starting at
+// (l % nseg) * seglen, so the template (I, Ix, Iy as int16 values) lives in registers for the whole
+// level and only the J patch is re-read per iteration, from an LDS-staged region.  The Scharr
+// derivative is fused: the wave stages the (win+3)^2 patch of I in LDS and derives the (win+1)^2
+// gradient patch there; no derivative image is ever written to HBM.
+// Sums of products are accumulated exactly (int32 per lane, int64 across the wave) and converted
+// to float32 once: order independent, equal to the oracle's ORC_ACC_EXACT mode bit for bit.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long wave_sum_i64(long long v) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+  return v;
+}
+
+__device__ __forceinline__ long long uniform_i64(long long v) {
+  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
+  return ((long long)hi << 32) | (unsigned int)lo;
+}
+
+__device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+  w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+  w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
+  w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
+  w11 = (1 << W_BITS) - w00 - w01 - w10;
+}
+
+#define VSF_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+// LDS carve-up per wave (bytes): sI (win+3)^2 padded pitch, sD (win+1)^2 * 4, sJ (win+1+2m)^2
+struct LkSmem {
+  int ip_pitch;  // sI pitch
+  int d_pitch;   // sD pitch (in int32)
+  int j_pitch;   // sJ pitch
+  int j_side;    // staged J region side
+  int off_d, off_j, total;
+};
+
+__host__ __device__ inline LkSmem lk_smem_layout(int win, int jmargin) {
+  LkSmem s;
+  s.ip_pitch = (win + 3 + 3) & ~3;
+  s.d_pitch = win + 1;
+  s.j_side = win + 1 + 2 * jmargin;
+  s.j_pitch = (s.j_side + 3) & ~3;
+  const int si = s.ip_pitch * (win + 3);
+  s.off_d = (si + 15) & ~15;
+  s.off_j = s.off_d + ((s.d_pitch * (win + 1) * 4 + 15) & ~15);
+  s.total = s.off_j + ((s.j_pitch * s.j_side + 15) & ~15);
+  return s;
+}
+
+// Tracks one point from pyramid A (template, derivatives) to pyramid B.  Wave-uniform control flow.
+// Returns the OpenCV status (true = found); out = nextPts.
+template <int SEG>
+__device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, float ptx, float pty,
+                               float& outx, float& outy, const LkParams& prm, uint8_t* smem,
+                               const LkSmem& L) {
+  const int lane = threadIdx.x & 63;
+  const int win = prm.win;
+  const int r = lane / prm.nseg;
+  const int x0 = (lane - r * prm.nseg) * prm.seglen;
+  const int cnt = (r < win) ? min(prm.seglen, win - x0) : 0;  // pixels this lane owns (may be <= 0)
+  uint8_t* sI = smem;
+  int* sD = reinterpret_cast<int*>(smem + L.off_d);
+  uint8_t* sJ = smem + L.off_j;
+  const float half = (float)(win - 1) * 0.5f;
+  const float FLT_SCALE = 1.f / (float)(1 << 20);
+  const int maxLevel = A.nlevels - 1;
+  bool status = true;
+  float nx = 0.f, ny = 0.f;  // nextPts
+
+  for (int level = maxLevel; level >= 0; level--) {
+    const float lscale = 1.f / (float)(1 << level);
+    float px = ptx * lscale, py = pty * lscale;
+    if (level == maxLevel) {
+      nx = px;
+      ny = py;
+    } else {
+      nx = nx * 2.f;
+      ny = ny * 2.f;
+    }
+    px -= half;
+    py -= half;
+    const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+    const int aw = A.w[level], ah = A.h[level];
+    if (ipx < -win || ipx >= aw || ipy < -win || ipy >= ah) {
+      if (level == 0) status = false;
+      continue;
+    }
+    int iw00, iw01, iw10, iw11;
+    bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
+
+    // ---- stage the (win+3)^2 patch of I (origin ipx-1, ipy-1), REFLECT_101 at the level border
+    {
+      const uint8_t* Ab = A.base[level] + (long long)stream * A.sstride[level];
+      const int ap = A.pitch[level];
+      const int side = win + 3;
+      for (int i = lane; i < side * side; i += 64) {
+        const int y = i / side, x = i - y * side;
+        const int gy = reflect101(ipy - 1 + y, ah), gx = reflect101(ipx - 1 + x, aw);
+        sI[y * L.ip_pitch + x] = Ab[(long long)gy * ap + gx];
+      }
+    }
+    __syncthreads();
+    // ---- Scharr gradient patch (win+1)^2, zero outside the level image (BORDER_CONSTANT)
+    {
+      const int side = win + 1;
+      for (int i = lane; i < side * side; i += 64) {
+        const int y = i / side, x = i - y * side;
+        const int gx = ipx + x, gy = ipy + y;
+        int packed = 0;
+        if (gx >= 0 && gx < aw && gy >= 0 && gy < ah) {
+          const uint8_t* c = sI + (y + 1) * L.ip_pitch + (x + 1);
+          const int p = L.ip_pitch;
+          const int i00 = c[-p - 1], i01 = c[-p], i02 = c[-p + 1];
+          const int i10 = c[-1], i12 = c[1];
+          const int i20 = c[p - 1], i21 = c[p], i22 = c[p + 1];
+          const int ix = 3 * (i02 - i00) + 10 * (i12 - i10) + 3 * (i22 - i20);
+          const int iy = 3 * (i20 - i00) + 10 * (i21 - i01) + 3 * (i22 - i02);
+          packed = (ix & 0xffff) | (iy << 16);
+        }
+        sD[y * L.d_pitch + x] = packed;
+      }
+    }
+    __syncthreads();
+    // ---- per-lane template (registers) and the normal matrix
+    int Iw[SEG], Ixw[SEG], Iyw[SEG];
+    int a11 = 0, a12 = 0, a22 = 0;
+    {
+      const uint8_t* c0 = sI + (r + 1) * L.ip_pitch + (x0 + 1);
+      const uint8_t* c1 = c0 + L.ip_pitch;
+      const int* d0 = sD + r * L.d_pitch + x0;
+      const int* d1 = d0 + L.d_pitch;
+#pragma unroll
+      for (int k = 0; k < SEG; k++) {
+        Iw[k] = 0;
+        Ixw[k] = 0;
+        Iyw[k] = 0;
+        if (k < cnt) {
+          const int ival = VSF_DESCALE((int)c0[k] * iw00 + (int)c0[k + 1] * iw01 + (int)c1[k] * iw10 +
+                                           (int)c1[k + 1] * iw11,
+                                       W_BITS - 5);
+          const int p00 = d0[k], p01 = d0[k + 1], p10 = d1[k], p11 = d1[k + 1];
+          const int ixval = VSF_DESCALE(((int)(short)(p00 & 0xffff)) * iw00 + ((int)(short)(p01 & 0xffff)) * iw01 +
+                                            ((int)(short)(p10 & 0xffff)) * iw10 +
+                                            ((int)(short)(p11 & 0xffff)) * iw11,
+                                        W_BITS);
+          const int iyval =
+              VSF_DESCALE((p00 >> 16) * iw00 + (p01 >> 16) * iw01 + (p10 >> 16) * iw10 + (p11 >> 16) * iw11,
+                          W_BITS);
+          Iw[k] = ival;
+          Ixw[k] = ixval;
+          Iyw[k] = iyval;
+          a11 += ixval * ixval;
+          a12 += ixval * iyval;
+          a22 += iyval * iyval;
+        }
+      }
+    }
+    const float A11 = (float)uniform_i64(wave_sum_i64(a11)) * FLT_SCALE;
+    const float A12 = (float)uniform_i64(wave_sum_i64(a12)) * FLT_SCALE;
+    const float A22 = (float)uniform_i64(wave_sum_i64(a22)) * FLT_SCALE;
+    float D = A11 * A22 - A12 * A12;
+    const float minEig =
+        (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+    if ((double)minEig < prm.min_eig_thr || D < 1.1920928955078125e-7f) {
+      if (level == 0) status = false;
+      continue;
+    }
+    D = 1.f / D;
+
+    // ---- iterations
+    const uint8_t* Bb = B.base[level] + (long long)stream * B.sstride[level];
+    const int bp = B.pitch[level], bw = B.w[level], bh = B.h[level];
+    float cx = nx - half, cy = ny - half;  // nextPt - halfWin
+    float pdx = 0.f, pdy = 0.f;
+    int jx0 = 0, jy0 = 0;
+    bool staged = false;
+    for (int j = 0; j < prm.max_count; j++) {
+      const int inx = (int)floorf(cx), iny = (int)floorf(cy);
+      if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
+        if (level == 0) status = false;
+        break;
+      }
+      if (!staged || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + L.j_side ||
+          iny + win + 1 > jy0 + L.j_side) {
+        __syncthreads();  // previous iteration's reads are done
+        jx0 = inx - prm.jmargin;
+        jy0 = iny - prm.jmargin;
+        for (int i = lane; i < L.j_side * L.j_side; i += 64) {
+          const int y = i / L.j_side, x = i - y * L.j_side;
+          const int gy = reflect101(jy0 + y, bh), gx = reflect101(jx0 + x, bw);
+          sJ[y * L.j_pitch + x] = Bb[(long long)gy * bp + gx];
+        }
+        staged = true;
+        __syncthreads();
+      }
+      bilinear_weights(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
+      int b1 = 0, b2 = 0;
+      {
+        const uint8_t* c0 = sJ + (r + iny - jy0) * L.j_pitch + (x0 + inx - jx0);
+        const uint8_t* c1 = c0 + L.j_pitch;
+#pragma unroll
+        for (int k = 0; k < SEG; k++) {
+          if (k < cnt) {
+            const int diff = VSF_DESCALE((int)c0[k] * iw00 + (int)c0[k + 1] * iw01 + (int)c1[k] * iw10 +
+                                             (int)c1[k + 1] * iw11,
+                                         W_BITS - 5) -
+                             Iw[k];
+            b1 += diff * Ixw[k];
+            b2 += diff * Iyw[k];
+          }
+        }
+      }
+      const float fb1 = (float)uniform_i64(wave_sum_i64(b1)) * FLT_SCALE;
+      const float fb2 = (float)uniform_i64(wave_sum_i64(b2)) * FLT_SCALE;
+      const float dx = (A12 * fb2 - A22 * fb1) * D;
+      const float dy = (A12 * fb1 - A11 * fb2) * D;
+      cx += dx;
+      cy += dy;
+      nx = cx + half;
+      ny = cy + half;
+      if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
+      if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+        nx -= dx * 0.5f;
+        ny -= dy * 0.5f;
+        break;
+      }
+      pdx = dx;
+      pdy = dy;
+    }
+    __syncthreads();  // LDS is reused by the next level
+    // cv: with err requested (the reference always passes an err vector) the final position is
+    // range-checked once more at level 0
+    if (status && level == 0) {
+      const int fx = (int)floorf(nx - half), fy = (int)floorf(ny - half);
+      if (fx < -win || fx >= bw || fy < -win || fy >= bh) status = false;
+    }
+  }
+  outx = nx;
+  outy = ny;
+  return status;
+}
+
+// flags bit0 = forward found, bit1 = backward found, bit2 = verified (kept).
+// ref: FeatureTrackerLucasKanade.cpp:36-80 (forward, backward on the forward survivors, then
+// ||back - original||_2 <= threshold in double against the ORIGINAL double position).
+template <int SEG>
+__global__ __launch_bounds__(64) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
+                                                   const int* __restrict__ n, int cap, LkParams prm,
+                                                   float2* __restrict__ fwd, uint8_t* __restrict__ flags) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int stream = blockIdx.y, f = blockIdx.x;
+  if (f >= n[stream]) return;
+  const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
+  const double2 p0 = xy[(long long)stream * cap + f];
+  const float p0x = (float)p0.x, p0y = (float)p0.y;  // :210 double -> float narrowing
+  float qx, qy;
+  uint8_t flag = 0;
+  if (lk_track_point<SEG>(P, C, stream, p0x, p0y, qx, qy, prm, smem, L)) {
+    flag |= 1;
+    float rx, ry;
+    if (lk_track_point<SEG>(C, P, stream, qx, qy, rx, ry, prm, smem, L)) {
+      flag |= 2;
+      const double ddx = (double)rx - p0.x, ddy = (double)ry - p0.y;
+      if (sqrt(ddx * ddx + ddy * ddy) <= prm.backtrack_thr) flag |= 4;
+    }
+  }
+  if ((threadIdx.x & 63) == 0) {
+    fwd[(long long)stream * cap + f] = make_float2(qx, qy);
+    flags[(long long)stream * cap + f] = flag;
+  }
+}
+
+// plain cv::calcOpticalFlowPyrLK on a point list (parity tests): one wave per point
+template <int SEG>
+__global__ __launch_bounds__(64) void lk_points_kernel(PyrView P, PyrView C, const float2* __restrict__ pts,
+                                                       int n, LkParams prm, float2* __restrict__ out,
+                                                       uint8_t* __restrict__ status) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
+  const float2 p = pts[f];
+  float qx, qy;
+  const bool st = lk_track_point<SEG>(P, C, 0, p.x, p.y, qx, qy, prm, smem, L);
+  if ((threadIdx.x & 63) == 0) {
+    out[f] = make_float2(qx, qy);
+    status[f] = st ? 1 : 0;
+  }
+}
+
+// Stable in-place compaction of one stream's table by the verified flag; also the three counts
+// the reference logs (FeatureTrackerLucasKanade.cpp:87-104).  One block of 256 threads per stream.
+__global__ __launch_bounds__(256) void compact_kernel(uint64_t* __restrict__ ids, double2* __restrict__ xy,
+                                                      uint32_t* __restrict__ age, int* __restrict__ n, int cap,
+                                                      const float2* __restrict__ fwd,
+                                                      const uint8_t* __restrict__ flags, int* __restrict__ stats) {
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  __shared__ int s_cnt[3];
+  const int stream = blockIdx.x;
+  const long long o = (long long)stream * cap;
+  const int n0 = n[stream];
+  if (threadIdx.x == 0) {
+    s_base = 0;
+    s_cnt[0] = s_cnt[1] = s_cnt[2] = 0;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c = 0; c < n0; c += 256) {
+    const int i = c + threadIdx.x;
+    uint8_t fl = 0;
+    uint64_t id = 0;
+    uint32_t ag = 0;
+    float2 q = make_float2(0.f, 0.f);
+    if (i < n0) {
+      fl = flags[o + i];
+      id = ids[o + i];
+      ag = age[o + i];
+      q = fwd[o + i];
+    }
+    const bool keep = (fl & 4) != 0;
+    const unsigned long long bal = __ballot(keep);
+    const unsigned long long bf = __ballot((fl & 1) != 0), bb = __ballot((fl & 2) != 0);
+    if (lane == 0) {
+      s_wave[wv] = __popcll(bal);
+      atomicAdd(&s_cnt[0], __popcll(bf));
+      atomicAdd(&s_cnt[1], __popcll(bb));
+      atomicAdd(&s_cnt[2], __popcll(bal));
+    }
+    __syncthreads();  // all reads of this chunk done, wave counts visible
+    int off = s_base;
+    for (int k = 0; k < wv; k++) off += s_wave[k];
+    off += __popcll(bal & ((1ull << lane) - 1ull));
+    if (keep) {
+      ids[o + off] = id;
+      age[o + off] = ag;
+      xy[o + off] = make_double2((double)q.x, (double)q.y);  // :231-232 float -> double
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    n[stream] = s_base;
+    stats[stream * 4 + 0] = n0;
+    stats[stream * 4 + 1] = s_cnt[0];
+    stats[stream * 4 + 2] = s_cnt[1];
+    stats[stream * 4 + 3] = s_cnt[2];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Detector (ref: FeatureDetectorShiTomasiBucketing.cpp:67-239; cv::goodFeaturesToTrack)
+// ------------------------------------------------------------------------------------------------
+struct GridView {
+  const int4* rects;      // [ncell] x, y, w, h (cvRound of the Rect2f, Q1)
+  const float2* origin;   // [ncell] unrounded Rect2f x, y (what :169 adds to the cell-local corner)
+  const int* lam_off;     // [ncell+1] offset of each cell's lambda map (floats)
+  int ncell, rows, cols;
+  int grid_max;           // max_feature_number / (rows*cols)  (Q3)
+  int lam_total;          // floats per stream
+};
+
+// Occupancy (Q4): number of distinct flagged pixels per cell, need per cell, and the number of
+// cells processed before the reference's early `break` (Q2).  One block per stream; an LDS hash
+// set de-duplicates pixels exactly like the reference's flag image.
+__global__ __launch_bounds__(256) void occupancy_kernel(const double2* __restrict__ xy, const int* __restrict__ n,
+                                                        int cap, GridView G, int w, int h, int hash_size,
+                                                        int* __restrict__ need, int* __restrict__ n_active,
+                                                        unsigned int* __restrict__ cell_max,
+                                                        int* __restrict__ cand_cnt) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  int* s_hash = reinterpret_cast<int*>(smem);
+  int* s_cnt = s_hash + hash_size;
+  const int stream = blockIdx.x;
+  const int n0 = n[stream];
+  for (int i = threadIdx.x; i < hash_size; i += 256) s_hash[i] = -1;
+  for (int i = threadIdx.x; i < G.ncell; i += 256) s_cnt[i] = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n0; i += 256) {
+    const double2 p = xy[(long long)stream * cap + i];
+    if (p.x > 0 && p.x < (double)w && p.y > 0 && p.y < (double)h) {  // :123-124 strict, in double
+      const int ix = (int)p.x, iy = (int)p.y;                        // :125 at<uint8_t>(pos[1], pos[0])
+      const int key = iy * w + ix;
+      unsigned int slot = ((unsigned int)key * 2654435761u) & (unsigned int)(hash_size - 1);
+      bool fresh = false;
+      for (;;) {
+        const int old = atomicCAS(&s_hash[slot], -1, key);
+        if (old == -1) {
+          fresh = true;
+          break;
+        }
+        if (old == key) break;
+        slot = (slot + 1) & (unsigned int)(hash_size - 1);
+      }
+      if (fresh) {
+        for (int c = 0; c < G.ncell; c++) {
+          const int4 rc = G.rects[c];
+          if (ix >= rc.x && ix < rc.x + rc.z && iy >= rc.y && iy < rc.y + rc.w) atomicAdd(&s_cnt[c], 1);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int act = G.ncell;
+    for (int c = 0; c < G.ncell; c++) {
+      const int q = G.grid_max - s_cnt[c];  // :152-153
+      need[stream * G.ncell + c] = q;
+      if (q <= 0 && act == G.ncell) act = c;  // :154 break
+    }
+    n_active[stream] = act;
+  }
+  for (int c = threadIdx.x; c < G.ncell; c += 256) {
+    cell_max[stream * G.ncell + c] = 0u;
+    cand_cnt[stream * G.ncell + c] = 0;
+  }
+}
+
+__device__ __forceinline__ unsigned int float_order_encode(float f) {
+  const unsigned int u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float float_order_decode(unsigned int e) {
+  return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
+}
+
+// Min-eigenvalue map of one grid cell tile (cv::cornerMinEigenVal on the cell ROI of the parent
+// image) + masked per-cell maximum.  Block = 64x16 pixels of one cell.
+// Sobel reads the parent image's real pixels (REFLECT_101 only at the true image border); the box
+// filter reflects at the CELL border and sums in double like cv::boxFilter does for 32F input.
+constexpr int SC_TW = 64, SC_TH = 16;
+constexpr int SC_IW = SC_TW + 4, SC_IH = SC_TH + 4;  // staged 8-bit tile (+2 halo)
+constexpr int SC_CW = SC_TW + 2, SC_CH = SC_TH + 2;  // covariance tile (+1 halo)
+constexpr int SC_IP = 72;
+
+__global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
+                                                    int row_stride, int w, int h,
+                                                    const uint8_t* __restrict__ masks, long long mask_sstride,
+                                                    int mask_row_stride, GridView G,
+                                                    const int* __restrict__ n_active, int tiles_x,
+                                                    float k_side, float k_mid, float* __restrict__ lam,
+                                                    unsigned int* __restrict__ cell_max) {
+  __shared__ uint8_t s_img[SC_IH * SC_IP];
+  __shared__ double s_cov[3][SC_CH * SC_CW];
+  __shared__ unsigned int s_max;
+  const int stream = blockIdx.z, cell = blockIdx.y;
+  if (cell >= n_active[stream]) return;
+  const int4 rc = G.rects[cell];
+  const int cw = rc.z, ch = rc.w;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int cx0 = tx * SC_TW, cy0 = ty * SC_TH;  // tile origin in cell coordinates
+  if (cx0 >= cw || cy0 >= ch) return;
+  const uint8_t* F = frames + (long long)stream * frame_sstride;
+  if (threadIdx.x == 0) s_max = 0u;
+  // staged image tile: parent coords [rc.x + cx0 - 2, +SC_IW) x [rc.y + cy0 - 2, +SC_IH)
+  const int gx0 = rc.x + cx0 - 2, gy0 = rc.y + cy0 - 2;
+  for (int i = threadIdx.x; i < SC_IH * SC_IW; i += 256) {
+    const int y = i / SC_IW, x = i - y * SC_IW;
+    const int gy = reflect101(gy0 + y, h), gx = reflect101(gx0 + x, w);
+    s_img[y * SC_IP + x] = F[(long long)gy * row_stride + gx];
+  }
+  __syncthreads();
+  // covariance at cell coords [cx0-1, cx0+SC_TW+1) x [cy0-1, cy0+SC_TH+1) that lie inside the cell
+  for (int i = threadIdx.x; i < SC_CH * SC_CW; i += 256) {
+    const int y = i / SC_CW, x = i - y * SC_CW;
+    const int cx = cx0 - 1 + x, cy = cy0 - 1 + y;
+    double vxx = 0, vxy = 0, vyy = 0;
+    if (cx >= 0 && cx < cw && cy >= 0 && cy < ch) {
+      const uint8_t* c = s_img + (y + 1) * SC_IP + (x + 1);
+      const int p = SC_IP;
+      const float r_m = (float)((int)c[-p + 1] - (int)c[-p - 1]);
+      const float r_0 = (float)((int)c[1] - (int)c[-1]);
+      const float r_p = (float)((int)c[p + 1] - (int)c[p - 1]);
+      const float dx = (r_m + r_p) * k_side + r_0 * k_mid;
+      float s_m = k_side * (float)c[-p - 1];
+      s_m += k_mid * (float)c[-p];
+      s_m += k_side * (float)c[-p + 1];
+      float s_p = k_side * (float)c[p - 1];
+      s_p += k_mid * (float)c[p];
+      s_p += k_side * (float)c[p + 1];
+      const float dy = s_p - s_m;
+      vxx = (double)(dx * dx);
+      vxy = (double)(dx * dy);
+      vyy = (double)(dy * dy);
+    }
+    s_cov[0][i] = vxx;
+    s_cov[1][i] = vxy;
+    s_cov[2][i] = vyy;
+  }
+  __syncthreads();
+  const uint8_t* M = masks ? masks + (long long)stream * mask_sstride : nullptr;
+  float* lam_cell = lam + (long long)stream * G.lam_total + G.lam_off[cell];
+  unsigned int local_max = 0u;
+  for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
+    const int y = i / SC_TW, x = i - y * SC_TW;
+    const int cx = cx0 + x, cy = cy0 + y;
+    if (cx < cw && cy < ch) {
+      double s[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        const int yy = reflect101(cy - 1 + j, ch) - (cy0 - 1);
+        const int xa = reflect101(cx - 1, cw) - (cx0 - 1), xb = cx - (cx0 - 1),
+                  xc = reflect101(cx + 1, cw) - (cx0 - 1);
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+          const double* row = s_cov[q] + yy * SC_CW;
+          const double rs = (row[xa] + row[xb]) + row[xc];
+          s[q] = (j == 0) ? rs : s[q] + rs;
+        }
+      }
+      const float a = (float)s[0] * 0.5f, b = (float)s[1], c = (float)s[2] * 0.5f;
+      const float lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+      lam_cell[cy * cw + cx] = lm;
+      if (!M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)]) {
+        const unsigned int e = float_order_encode(lm);
+        local_max = max(local_max, e);
+      }
+    }
+  }
+  // wave max, then one LDS atomic per wave, one global atomic per block
+  for (int m = 32; m >= 1; m >>= 1) local_max = max(local_max, (unsigned int)__shfl_xor((int)local_max, m, 64));
+  if ((threadIdx.x & 63) == 0 && local_max) atomicMax(&s_max, local_max);
+  __syncthreads();
+  if (threadIdx.x == 0 && s_max) atomicMax(&cell_max[stream * G.ncell + cell], s_max);
+}
+
+// Threshold at quality*max, 3x3 local maximum, interior of the cell only;
+// survivors are appended to the cell's candidate list as keys (lambda bits << 32 | raster index),
+// whose unsigned order is exactly cv's greaterThanPtr order (value, then address).
+__global__ __launch_bounds__(256) void candidate_kernel(const float* __restrict__ lam, GridView G,
+                                                        const int* __restrict__ n_active, int tiles_x,
+                                                        const unsigned int* __restrict__ cell_max, double quality,
+                                                        const uint8_t* __restrict__ masks, long long mask_sstride,
+                                                        int mask_row_stride, unsigned long long* __restrict__ cand,
+                                                        int cand_cap, int* __restrict__ cand_cnt) {
+  const int stream = blockIdx.z, cell = blockIdx.y;
+  if (cell >= n_active[stream]) return;
+  const int4 rc = G.rects[cell];
+  const int cw = rc.z, ch = rc.w;
+  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+  const int cx0 = tx * SC_TW, cy0 = ty * SC_TH;
+  if (cx0 >= cw || cy0 >= ch) return;
+  const unsigned int enc = cell_max[stream * G.ncell + cell];
+  const double maxVal = enc ? (double)float_order_decode(enc) : 0.0;
+  const float thr = (float)(maxVal * quality);
+  const float* L = lam + (long long)stream * G.lam_total + G.lam_off[cell];
+  const uint8_t* M = masks ? masks + (long long)stream * mask_sstride : nullptr;
+  for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
+    const int y = i / SC_TW, x = i - y * SC_TW;
+    const int cx = cx0 + x, cy = cy0 + y;
+    if (cx >= 1 && cx < cw - 1 && cy >= 1 && cy < ch - 1) {
+      float v = L[cy * cw + cx];
+      v = v > thr ? v : 0.f;
+      if (v != 0.f) {
+        float m = v;
+#pragma unroll
+        for (int j = -1; j <= 1; j++)
+#pragma unroll
+          for (int q = -1; q <= 1; q++) {
+            float t = L[(cy + j) * cw + (cx + q)];
+            t = t > thr ? t : 0.f;
+            m = fmaxf(m, t);
+          }
+        if (v == m && (!M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)])) {
+          const int slot = atomicAdd(&cand_cnt[stream * G.ncell + cell], 1);
+          if (slot < cand_cap)
+            cand[((long long)stream * G.ncell + cell) * cand_cap + slot] =
+                ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)(cy * cw + cx);
+        }
+      }
+    }
+  }
+}
+
+// Greedy min-distance selection + the reference's nearest-neighbour
+// rejection against PRE-EXISTING features (Q5).  One block per (stream, cell).
+// "Visit candidates in sorted order, accept when no accepted corner is closer than minDist" is
+// evaluated as "repeatedly take the largest remaining key, then drop everything within minDist of
+// it": the same accepted sequence, without a sort.  When the candidate list overflowed cand_cap
+// the same loop runs over the whole lambda map instead (slow, exact).
+struct SelParams {
+  double min_dist;   // detector min_feature_distance
+  double quality;
+  int cap;           // table capacity
+  int cand_cap;
+  int sel_cap;       // accepted-corner slots per cell (= grid_max)
+};
+
+__global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ lam, GridView G,
+                                                     const int* __restrict__ n_active,
+                                                     const int* __restrict__ need,
+                                                     const unsigned int* __restrict__ cell_max,
+                                                     const uint8_t* __restrict__ masks, long long mask_sstride,
+                                                     int mask_row_stride,
+                                                     const unsigned long long* __restrict__ cand,
+                                                     const int* __restrict__ cand_cnt, SelParams sp,
+                                                     const double2* __restrict__ xy, const int* __restrict__ n,
+                                                     double2* __restrict__ sel_xy, int* __restrict__ sel_cnt) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);  // [cand_cap], 0 = dead
+  int* s_acc_x = reinterpret_cast<int*>(s_key + sp.cand_cap);               // [sel_cap]
+  int* s_acc_y = s_acc_x + sp.sel_cap;                                      // [sel_cap]
+  int* s_ok = s_acc_y + sp.sel_cap;                                         // [sel_cap]
+  __shared__ unsigned long long s_red[4];
+  const int stream = blockIdx.y, cell = blockIdx.x;
+  const int sc = stream * G.ncell + cell;
+  if (cell >= n_active[stream]) {
+    if (threadIdx.x == 0) sel_cnt[sc] = 0;
+    return;
+  }
+  const int4 rc = G.rects[cell];
+  const int cw = rc.z, ch = rc.w;
+  const int want = min(need[sc], sp.sel_cap);
+  const int total = cand_cnt[sc];
+  const bool overflow = total > sp.cand_cap;
+  const int M = overflow ? cw * ch : total;
+  const float* L = lam + (long long)stream * G.lam_total + G.lam_off[cell];
+  const uint8_t* Mk = masks ? masks + (long long)stream * mask_sstride : nullptr;
+  const unsigned int enc = cell_max[sc];
+  const float thr = (float)((enc ? (double)float_order_decode(enc) : 0.0) * sp.quality);
+  const double md2 = sp.min_dist * sp.min_dist;  // cv: minDistance *= minDistance (double)
+  const bool use_dist = sp.min_dist >= 1.0;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+  if (!overflow)
+    for (int i = threadIdx.x; i < M; i += 256) s_key[i] = cand[(long long)sc * sp.cand_cap + i];
+  __syncthreads();
+
+  int accepted = 0;
+  int lastx = -1000000, lasty = -1000000;
+  unsigned long long lastkey = ~0ull;
+  while (accepted < want) {
+    // ---- arg-max over the remaining candidates
+    unsigned long long best = 0ull;
+    if (!overflow) {
+      // fast path: the suppression by the last accepted corner is folded into the scan
+      for (int i = threadIdx.x; i < M; i += 256) {
+        const unsigned long long k = s_key[i];
+        if (k) {
+          const int idx = (int)(k & 0xffffffffull);
+          const int y = idx / cw, x = idx - y * cw;
+          const float ddx = (float)x - (float)lastx, ddy = (float)y - (float)lasty;
+          const bool dead = (k == lastkey) || (use_dist && (double)(ddx * ddx + ddy * ddy) < md2);
+          if (dead)
+            s_key[i] = 0ull;
+          else if (k > best)
+            best = k;
+        }
+      }
+    } else {
+      // overflow path: candidates are re-derived from the lambda map; keys are unique and visited in
+      // descending order, so everything >= lastkey has been decided already
+      for (int i = threadIdx.x; i < M; i += 256) {
+        const int y = i / cw, x = i - y * cw;
+        if (x < 1 || x >= cw - 1 || y < 1 || y >= ch - 1) continue;
+        float v = L[i];
+        v = v > thr ? v : 0.f;
+        if (v == 0.f) continue;
+        const unsigned long long k = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)i;
+        if (k >= lastkey || k <= best) continue;
+        float m = v;
+        for (int j = -1; j <= 1; j++)
+          for (int q = -1; q <= 1; q++) {
+            float t = L[(y + j) * cw + (x + q)];
+            t = t > thr ? t : 0.f;
+            m = fmaxf(m, t);
+          }
+        if (v != m) continue;
+        if (Mk && !Mk[(long long)(rc.y + y) * mask_row_stride + (rc.x + x)]) continue;
+        bool dead = false;
+        if (use_dist)
+          for (int a = 0; a < accepted && !dead; a++) {
+            const float ddx = (float)x - (float)s_acc_x[a], ddy = (float)y - (float)s_acc_y[a];
+            dead = (double)(ddx * ddx + ddy * ddy) < md2;
+          }
+        if (!dead) best = k;
+      }
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+      const unsigned long long o = __shfl_xor(best, m, 64);
+      best = o > best ? o : best;
+    }
+    __syncthreads();
+    if (lane == 0) s_red[wv] = best;
+    __syncthreads();
+    best = s_red[0];
+    for (int k = 1; k < 4; k++) best = s_red[k] > best ? s_red[k] : best;
+    if (best == 0ull) break;
+    const int idx = (int)(best & 0xffffffffull);
+    lasty = idx / cw;
+    lastx = idx - lasty * cw;
+    lastkey = best;
+    if (threadIdx.x == 0) {
+      s_acc_x[accepted] = lastx;
+      s_acc_y[accepted] = lasty;
+    }
+    accepted++;
+    __syncthreads();  // s_acc visible to the overflow path's distance test
+  }
+  // ---- NN rejection against the pre-existing features (Q5), in double; all of them, in or out of
+  // the image (:127).  kd-tree nearest_point == exact minimum distance (kdtree/KDTree.cpp:154-233).
+  const int n0 = n[stream];
+  const float2 org = G.origin[cell];
+  for (int a = threadIdx.x; a < accepted; a += 256) s_ok[a] = 1;
+  __syncthreads();
+  for (int t = threadIdx.x; t < accepted * n0; t += 256) {
+    const int a = t / n0, i = t - a * n0;
+    const double px = (double)((float)s_acc_x[a] + org.x), py = (double)((float)s_acc_y[a] + org.y);
+    const double2 e = xy[(long long)stream * sp.cap + i];
+    const double ddx = px - e.x, ddy = py - e.y;
+    if (!(sqrt(ddx * ddx + ddy * ddy) > sp.min_dist)) s_ok[a] = 0;  // :178-180 keep iff norm > minDist
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int written = 0;
+    for (int a = 0; a < accepted; a++)
+      if (s_ok[a]) {
+        // :169 kp.pt.x + grect.x in float with the unrounded Rect2f origin, then widened
+        sel_xy[(long long)sc * sp.sel_cap + written] =
+            make_double2((double)((float)s_acc_x[a] + org.x), (double)((float)s_acc_y[a] + org.y));
+        written++;
+      }
+    sel_cnt[sc] = written;
+  }
+}
+
+// Id assignment and upsert (Q6, Q7; ref :142, :173-184, :238).  One block per stream.
+// New ids are the contiguous range [start, start+K) mod 2^64 in column-major cell order; an id that
+// already exists is overwritten in place (unordered_map::operator[]), the rest are appended.
+__global__ __launch_bounds__(256) void append_kernel(GridView G, const int* __restrict__ n_active,
+                                                     const double2* __restrict__ sel_xy,
+                                                     const int* __restrict__ sel_cnt, int sel_cap,
+                                                     uint64_t* __restrict__ ids, double2* __restrict__ xy,
+                                                     uint32_t* __restrict__ age, int* __restrict__ n, int cap,
+                                                     uint64_t* __restrict__ max_feature_index,
+                                                     int* __restrict__ status) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  int* s_off = reinterpret_cast<int*>(smem);       // [ncell+1] prefix of selected counts
+  int* s_slot = s_off + (G.ncell + 1);             // [K] slot of each new feature (-1 = append)
+  __shared__ int s_wave[4];
+  __shared__ int s_base;
+  const int stream = blockIdx.x;
+  const int act = n_active[stream];
+  if (threadIdx.x == 0) {
+    int o = 0;
+    for (int c = 0; c < G.ncell; c++) {
+      s_off[c] = o;
+      if (c < act) o += sel_cnt[stream * G.ncell + c];
+    }
+    s_off[G.ncell] = o;
+  }
+  __syncthreads();
+  const int K = s_off[G.ncell];
+  const uint64_t start = max_feature_index[stream];
+  const int n0 = n[stream];
+  const long long o = (long long)stream * cap;
+  for (int k = threadIdx.x; k < K; k += 256) s_slot[k] = -1;
+  __syncthreads();
+  for (int i = threadIdx.x; i < n0; i += 256) {
+    const uint64_t d = ids[o + i] - start;  // wraps like the reference's uint64 counter
+    if (d < (uint64_t)K) s_slot[(int)d] = i;
+  }
+  __syncthreads();
+  // stable ranks of the appended ones
+  if (threadIdx.x == 0) s_base = n0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int c0 = 0; c0 < K; c0 += 256) {
+    const int k = c0 + threadIdx.x;
+    const bool app = (k < K) && (s_slot[k] < 0);
+    const unsigned long long bal = __ballot(app);
+    if (lane == 0) s_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int off = s_base;
+    for (int q = 0; q < wv; q++) off += s_wave[q];
+    off += __popcll(bal & ((1ull << lane) - 1ull));
+    if (app) s_slot[k] = off;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+    __syncthreads();
+  }
+  // scatter: cell of k by scanning the prefix (ncell is small)
+  for (int k = threadIdx.x; k < K; k += 256) {
+    int c = 0;
+    while (s_off[c + 1] <= k) c++;
+    const int slot = s_slot[k];
+    if (slot < cap) {
+      ids[o + slot] = start + (uint64_t)k;
+      xy[o + slot] = sel_xy[((long long)stream * G.ncell + c) * sel_cap + (k - s_off[c])];
+      age[o + slot] = 1u;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int nn = s_base;
+    if (nn > cap) {
+      nn = cap;
+      status[stream] = -3;  // VSF_E_CAPACITY
+    }
+    n[stream] = nn;
+    max_feature_index[stream] = start + (uint64_t)K - 1ull;  // :238 feature_index - 1 (wraps)
+  }
+}
+
+}  // namespace vsf
