@@ -51,7 +51,7 @@ typedef struct vsf_params {
   /* FeatureTrackerLucasKanade ctor (FeatureTrackerLucasKanade.hpp:19-23) */
   int32_t klt_max_iter;   /* klt_max_iteration */
   double klt_eps;         /* klt_epsilon */
-  int32_t klt_win;        /* klt_window_size (square), 3..32 */
+  int32_t klt_win;        /* klt_window_size (square), 3..31 */
   int32_t klt_max_level;  /* klt_max_level, 0..7 */
   double min_eig_thr;     /* 1e-4, cv::calcOpticalFlowPyrLK default */
   double backtrack_thr;   /* backtrack_distance_threshold */
@@ -128,6 +128,10 @@ int vsf_batch_download(vsf_ctx* ctx, int32_t first, int32_t count, uint64_t* ids
  * u64, xy [streams][capacity][2] f64, age [streams][capacity] u32, n [streams] i32. */
 int vsf_batch_device_tables(vsf_ctx* ctx, void** ids, void** xy, void** age, void** n,
                             int32_t* capacity);
+/* Packs every stream's table into fixed-size 24-byte records {u64 id; f32 x, y; u32 age; u32 valid}
+ * [streams][capacity] in the caller's device buffer (streams*capacity*24 bytes), padded with
+ * valid = 0, for the RCCL gather of tracks.  Enqueues one kernel on hip_stream. */
+int vsf_batch_export_tracks(vsf_ctx* ctx, void* d_records, void* hip_stream);
 /* Sticky per-stream device status of the batched calls: 0 or VSF_E_CAPACITY.  Synchronous. */
 int vsf_batch_status(vsf_ctx* ctx, int32_t* status /* [streams] */);
 /* Forget the previous frame (next vsf_batch_track / vsf_track only stores its frame). */

@@ -25,6 +25,7 @@ ABI_SYMBOLS = [
     "vsf_track", "vsf_track_pair", "vsf_detect", "vsf_get_max_feature_index",
     "vsf_set_max_feature_index", "vsf_batch_track", "vsf_batch_detect", "vsf_batch_step",
     "vsf_batch_upload", "vsf_batch_download", "vsf_batch_device_tables", "vsf_batch_status",
+    "vsf_batch_export_tracks",
     "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig",
     "vsf_profile_enable", "vsf_profile_read",
 ]
@@ -198,6 +199,9 @@ class Context:
         self._chk(lib().vsf_batch_device_tables(self._h, C.byref(p[0]), C.byref(p[1]), C.byref(p[2]),
                                                 C.byref(p[3]), C.byref(cap)))
         return [x.value for x in p], cap.value
+
+    def batch_export_tracks(self, d_records, stream=0):
+        self._chk(lib().vsf_batch_export_tracks(self._h, C.c_void_p(d_records), C.c_void_p(stream)))
 
     def batch_status(self):
         st = np.zeros(self.streams, np.int32)

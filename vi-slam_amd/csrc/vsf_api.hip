@@ -748,6 +748,17 @@ int vsf_batch_device_tables(vsf_ctx* c, void** ids, void** xy, void** age, void*
   return VSF_OK;
 }
 
+int vsf_batch_export_tracks(vsf_ctx* c, void* d_records, void* hip_stream) {
+  if (!c || !d_records) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  const long long total = (long long)c->B * c->cap;
+  hipLaunchKernelGGL(export_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(hip_stream), c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, total,
+                     reinterpret_cast<TrackRecord*>(d_records));
+  HIPCHK(c, hipGetLastError());
+  return VSF_OK;
+}
+
 int vsf_batch_status(vsf_ctx* c, int32_t* status) {
   if (!c || !status) return VSF_E_INVALID;
   HIPCHK(c, hipSetDevice(c->p.device_id));

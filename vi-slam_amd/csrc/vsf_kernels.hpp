@@ -18,7 +18,7 @@
 namespace vsf {
 
 constexpr int MAXL = 8;      // pyramid levels supported (klt_max_level <= 7)
-constexpr int MAX_WIN = 32;  // LK window side supported
+constexpr int MAX_WIN = 31;  // LK window side supported
 constexpr int W_BITS = 14;
 
 struct PyrView {
@@ -99,16 +99,28 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict
 // Sums of products are accumulated exactly (int32 per lane, int64 across the wave) and converted
 // to float32 once: order independent, equal to the oracle's ORC_ACC_EXACT mode bit for bit.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ long long wave_sum_i64(long long v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+// ---- exact wave-wide integer sums -------------------------------------------------------------
+// Every lane ends up holding the sum of its 16-lane row; DPP adds, no LDS traffic.
+__device__ __forceinline__ int row_sum_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
   return v;
 }
-
-__device__ __forceinline__ long long uniform_i64(long long v) {
-  const int lo = __builtin_amdgcn_readfirstlane((int)(v & 0xffffffffll));
-  const int hi = __builtin_amdgcn_readfirstlane((int)(v >> 32));
-  return ((long long)hi << 32) | (unsigned int)lo;
+// Wave-uniform (scalar) sum of a per-lane int32; the caller guarantees no overflow.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v = row_sum_dpp(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+// float32(sum over the wave of p), correctly rounded from the EXACT integer sum: the per-lane value
+// is split into a 16-bit low limb and a signed high limb so that both 64-lane sums fit int32; the
+// recombination in double is exact (< 2^53) and rounds to float32 once.
+__device__ __forceinline__ float wave_sum_exact_f32(int p) {
+  const int slo = wave_sum_i32(p & 0xffff);
+  const int shi = wave_sum_i32(p >> 16);
+  return (float)((double)shi * 65536.0 + (double)slo);
 }
 
 __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
@@ -120,26 +132,109 @@ __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int
 
 #define VSF_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
 
-// LDS carve-up per wave (bytes): sI (win+3)^2 padded pitch, sD (win+1)^2 * 4, sJ (win+1+2m)^2
+typedef short vsf_i16x2 __attribute__((ext_vector_type(2)));
+
+// a.lo*b.lo + a.hi*b.hi + c on packed SIGNED 16-bit pairs (v_dot2_i32_i16).  Signed because the
+// fourth bilinear weight, 2^14 - w00 - w01 - w10, can come out as -1 after rounding.
+__device__ __forceinline__ int sdot2(unsigned int a, unsigned int b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(vsf_i16x2, a), __builtin_bit_cast(vsf_i16x2, b), c, false);
+}
+
+// Reads NA+... dwords of an LDS byte row starting at byte offset `boff` and returns, in A[], the byte
+// stream re-aligned so that A[0] byte 0 is the byte at `boff`.
+template <int NA>
+__device__ __forceinline__ void lds_stream(const uint8_t* row, int boff, unsigned int (&A)[NA]) {
+  const unsigned int* w = reinterpret_cast<const unsigned int*>(row) + (boff >> 2);
+  const unsigned int o = (unsigned int)boff & 3u;
+  unsigned int d[NA + 1];
+#pragma unroll
+  for (int i = 0; i < NA + 1; i++) d[i] = w[i];
+#pragma unroll
+  for (int i = 0; i < NA; i++) A[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], o);
+}
+
+// (byte k) | (byte k+1) << 16 of a dword stream (v_perm_b32; selector 0x0c = zero byte)
+template <int K, int NA>
+__device__ __forceinline__ unsigned int byte_pair(const unsigned int (&A)[NA]) {
+  constexpr int j = K >> 2, m = K & 3;
+  if constexpr (m < 3) {
+    return __builtin_amdgcn_perm(0u, A[j], 0x0c000c00u | (unsigned int)m | ((unsigned int)(m + 1) << 16));
+  } else {
+    return __builtin_amdgcn_perm(A[j + 1], A[j], 0x0c040c03u);
+  }
+}
+
+template <int K, int SEG, int NA>
+struct BilinearRow {
+  // out[k] = sum over the 2x2 neighbourhood, for k = K..SEG-1 (compile-time recursion keeps every
+  // index a constant, so the arrays stay in registers)
+  static __device__ __forceinline__ void run(const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
+                                             unsigned int W0, unsigned int W1, int (&out)[SEG]) {
+    out[K] = sdot2(byte_pair<K, NA>(A1), W1, sdot2(byte_pair<K, NA>(A0), W0, 0));
+    if constexpr (K + 1 < SEG) BilinearRow<K + 1, SEG, NA>::run(A0, A1, W0, W1, out);
+  }
+};
+
+// LDS carve-up per wave (bytes)
 struct LkSmem {
-  int ip_pitch;  // sI pitch
-  int d_pitch;   // sD pitch (in int32)
-  int j_pitch;   // sJ pitch
-  int j_side;    // staged J region side
+  int i_pitch, i_rows, i_ndw_log2;  // template patch of I: rows = win+3
+  int d_pitch;                      // gradient patch (win+1)^2, packed (Ix | Iy<<16) int32
+  int j_pitch, j_rows, j_ndw_log2;  // staged J region
   int off_d, off_j, total;
 };
 
+__host__ __device__ inline int vsf_log2_ceil(int v) {
+  int l = 0;
+  while ((1 << l) < v) l++;
+  return l;
+}
+
 __host__ __device__ inline LkSmem lk_smem_layout(int win, int jmargin) {
   LkSmem s;
-  s.ip_pitch = (win + 3 + 3) & ~3;
+  s.i_pitch = ((win + 9) / 4) * 4;  // covers (win+3) columns at any 4-byte phase of the origin
+  s.i_rows = win + 3;
+  s.i_ndw_log2 = vsf_log2_ceil(s.i_pitch / 4);
   s.d_pitch = win + 1;
-  s.j_side = win + 1 + 2 * jmargin;
-  s.j_pitch = (s.j_side + 3) & ~3;
-  const int si = s.ip_pitch * (win + 3);
+  s.j_pitch = ((win + 1 + 2 * jmargin + 3 + 3) / 4) * 4;
+  s.j_rows = win + 1 + 2 * jmargin;
+  s.j_ndw_log2 = vsf_log2_ceil(s.j_pitch / 4);
+  const int si = s.i_pitch * s.i_rows + 32;  // +slack: dword-granular readers may run past a row end
   s.off_d = (si + 15) & ~15;
   s.off_j = s.off_d + ((s.d_pitch * (win + 1) * 4 + 15) & ~15);
-  s.total = s.off_j + ((s.j_pitch * s.j_side + 15) & ~15);
+  s.total = s.off_j + ((s.j_pitch * s.j_rows + 32 + 15) & ~15);
   return s;
+}
+
+// Stages rows [y0, y0+rows) x byte columns [xa, xa+pitch) (xa a multiple of 4) of a level into LDS.
+// Interior regions are fetched as aligned dwords; regions touching the border go byte by byte with
+// REFLECT_101 indexing (values identical to OpenCV's reflect-padded pyramid level).
+__device__ __forceinline__ void stage_region(uint8_t* dst, int pitch, int rows, int ndw_log2,
+                                             const uint8_t* __restrict__ src, int sp, int sw, int sh, int xa,
+                                             int y0, int lane) {
+  const int ndw = pitch >> 2;
+  const int xd = lane & ((1 << ndw_log2) - 1), yl = lane >> ndw_log2, ystep = 64 >> ndw_log2;
+  const bool interior = xa >= 0 && y0 >= 0 && xa + pitch <= sw && y0 + rows <= sh && (sp & 3) == 0 &&
+                        ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+  if (interior) {
+    if (xd < ndw) {
+      const unsigned int* s = reinterpret_cast<const unsigned int*>(src + (long long)y0 * sp + xa) + xd;
+      unsigned int* d = reinterpret_cast<unsigned int*>(dst) + xd;
+      const int spw = sp >> 2;
+      for (int y = yl; y < rows; y += ystep) d[y * ndw] = s[(long long)y * spw];
+    }
+  } else {
+    if (xd < ndw) {
+      int gx[4];
+#pragma unroll
+      for (int b = 0; b < 4; b++) gx[b] = reflect101(xa + 4 * xd + b, sw);
+      unsigned int* d = reinterpret_cast<unsigned int*>(dst) + xd;
+      for (int y = yl; y < rows; y += ystep) {
+        const uint8_t* sr = src + (long long)reflect101(y0 + y, sh) * sp;
+        d[y * ndw] = (unsigned int)sr[gx[0]] | ((unsigned int)sr[gx[1]] << 8) | ((unsigned int)sr[gx[2]] << 16) |
+                     ((unsigned int)sr[gx[3]] << 24);
+      }
+    }
+  }
 }
 
 // Tracks one point from pyramid A (template, derivatives) to pyramid B.  Wave-uniform control flow.
@@ -148,11 +243,14 @@ template <int SEG>
 __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, float ptx, float pty,
                                float& outx, float& outy, const LkParams& prm, uint8_t* smem,
                                const LkSmem& L) {
+  constexpr int NA = (SEG + 1 + 3) / 4;  // aligned dwords holding SEG+1 bytes
   const int lane = threadIdx.x & 63;
   const int win = prm.win;
   const int r = lane / prm.nseg;
   const int x0 = (lane - r * prm.nseg) * prm.seglen;
-  const int cnt = (r < win) ? min(prm.seglen, win - x0) : 0;  // pixels this lane owns (may be <= 0)
+  const bool owner = (r < win) && (x0 < win);                // lane owns at least one window pixel
+  const int cnt = owner ? min(prm.seglen, win - x0) : 0;
+  const int rr = owner ? r : 0, xx0 = owner ? x0 : 0;        // idle lanes read a valid (unused) place
   uint8_t* sI = smem;
   int* sD = reinterpret_cast<int*>(smem + L.off_d);
   uint8_t* sJ = smem + L.off_j;
@@ -183,36 +281,34 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     int iw00, iw01, iw10, iw11;
     bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
 
-    // ---- stage the (win+3)^2 patch of I (origin ipx-1, ipy-1), REFLECT_101 at the level border
-    {
-      const uint8_t* Ab = A.base[level] + (long long)stream * A.sstride[level];
-      const int ap = A.pitch[level];
-      const int side = win + 3;
-      for (int i = lane; i < side * side; i += 64) {
-        const int y = i / side, x = i - y * side;
-        const int gy = reflect101(ipy - 1 + y, ah), gx = reflect101(ipx - 1 + x, aw);
-        sI[y * L.ip_pitch + x] = Ab[(long long)gy * ap + gx];
-      }
-    }
+    // ---- stage the (win+3)-row patch of I; its column origin xaI is (ipx-1) rounded down to 4
+    const int xaI = (ipx - 1) & ~3;
+    const int oI = (ipx - 1) - xaI;
+    stage_region(sI, L.i_pitch, L.i_rows, L.i_ndw_log2, A.base[level] + (long long)stream * A.sstride[level],
+                 A.pitch[level], aw, ah, xaI, ipy - 1, lane);
     __syncthreads();
     // ---- Scharr gradient patch (win+1)^2, zero outside the level image (BORDER_CONSTANT)
     {
       const int side = win + 1;
-      for (int i = lane; i < side * side; i += 64) {
-        const int y = i / side, x = i - y * side;
-        const int gx = ipx + x, gy = ipy + y;
-        int packed = 0;
-        if (gx >= 0 && gx < aw && gy >= 0 && gy < ah) {
-          const uint8_t* c = sI + (y + 1) * L.ip_pitch + (x + 1);
-          const int p = L.ip_pitch;
-          const int i00 = c[-p - 1], i01 = c[-p], i02 = c[-p + 1];
-          const int i10 = c[-1], i12 = c[1];
-          const int i20 = c[p - 1], i21 = c[p], i22 = c[p + 1];
-          const int ix = 3 * (i02 - i00) + 10 * (i12 - i10) + 3 * (i22 - i20);
-          const int iy = 3 * (i20 - i00) + 10 * (i21 - i01) + 3 * (i22 - i02);
-          packed = (ix & 0xffff) | (iy << 16);
+      const int xs = lane & 31;
+      if (xs < side) {
+        const int gx = ipx + xs;
+        const bool xin = gx >= 0 && gx < aw;
+        for (int y = lane >> 5; y < side; y += 2) {
+          const int gy = ipy + y;
+          int packed = 0;
+          if (xin && gy >= 0 && gy < ah) {
+            const uint8_t* c = sI + (y + 1) * L.i_pitch + (oI + xs + 1);
+            const int p = L.i_pitch;
+            const int i00 = c[-p - 1], i01 = c[-p], i02 = c[-p + 1];
+            const int i10 = c[-1], i12 = c[1];
+            const int i20 = c[p - 1], i21 = c[p], i22 = c[p + 1];
+            const int ix = 3 * (i02 - i00) + 10 * (i12 - i10) + 3 * (i22 - i20);
+            const int iy = 3 * (i20 - i00) + 10 * (i21 - i01) + 3 * (i22 - i02);
+            packed = (ix & 0xffff) | (iy << 16);
+          }
+          sD[y * L.d_pitch + xs] = packed;
         }
-        sD[y * L.d_pitch + x] = packed;
       }
     }
     __syncthreads();
@@ -220,39 +316,39 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     int Iw[SEG], Ixw[SEG], Iyw[SEG];
     int a11 = 0, a12 = 0, a22 = 0;
     {
-      const uint8_t* c0 = sI + (r + 1) * L.ip_pitch + (x0 + 1);
-      const uint8_t* c1 = c0 + L.ip_pitch;
-      const int* d0 = sD + r * L.d_pitch + x0;
+      unsigned int R0[NA], R1[NA];
+      lds_stream<NA>(sI + (rr + 1) * L.i_pitch, oI + 1 + xx0, R0);
+      lds_stream<NA>(sI + (rr + 2) * L.i_pitch, oI + 1 + xx0, R1);
+      const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
+      const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
+      BilinearRow<0, SEG, NA>::run(R0, R1, W0, W1, Iw);
+      const int* d0 = sD + rr * L.d_pitch + xx0;
       const int* d1 = d0 + L.d_pitch;
 #pragma unroll
       for (int k = 0; k < SEG; k++) {
-        Iw[k] = 0;
-        Ixw[k] = 0;
-        Iyw[k] = 0;
+        Iw[k] = VSF_DESCALE(Iw[k], W_BITS - 5);
+        int ixval = 0, iyval = 0;
         if (k < cnt) {
-          const int ival = VSF_DESCALE((int)c0[k] * iw00 + (int)c0[k + 1] * iw01 + (int)c1[k] * iw10 +
-                                           (int)c1[k + 1] * iw11,
-                                       W_BITS - 5);
           const int p00 = d0[k], p01 = d0[k + 1], p10 = d1[k], p11 = d1[k + 1];
-          const int ixval = VSF_DESCALE(((int)(short)(p00 & 0xffff)) * iw00 + ((int)(short)(p01 & 0xffff)) * iw01 +
-                                            ((int)(short)(p10 & 0xffff)) * iw10 +
-                                            ((int)(short)(p11 & 0xffff)) * iw11,
-                                        W_BITS);
-          const int iyval =
-              VSF_DESCALE((p00 >> 16) * iw00 + (p01 >> 16) * iw01 + (p10 >> 16) * iw10 + (p11 >> 16) * iw11,
-                          W_BITS);
-          Iw[k] = ival;
-          Ixw[k] = ixval;
-          Iyw[k] = iyval;
-          a11 += ixval * ixval;
-          a12 += ixval * iyval;
-          a22 += iyval * iyval;
+          ixval = VSF_DESCALE(__mul24((int)(short)(p00 & 0xffff), iw00) + __mul24((int)(short)(p01 & 0xffff), iw01) +
+                                  __mul24((int)(short)(p10 & 0xffff), iw10) +
+                                  __mul24((int)(short)(p11 & 0xffff), iw11),
+                              W_BITS);
+          iyval = VSF_DESCALE(__mul24(p00 >> 16, iw00) + __mul24(p01 >> 16, iw01) + __mul24(p10 >> 16, iw10) +
+                                  __mul24(p11 >> 16, iw11),
+                              W_BITS);
         }
+        // pixels a lane does not own carry zero gradients, so they add nothing to any sum
+        Ixw[k] = ixval;
+        Iyw[k] = iyval;
+        a11 += __mul24(ixval, ixval);
+        a12 += __mul24(ixval, iyval);
+        a22 += __mul24(iyval, iyval);
       }
     }
-    const float A11 = (float)uniform_i64(wave_sum_i64(a11)) * FLT_SCALE;
-    const float A12 = (float)uniform_i64(wave_sum_i64(a12)) * FLT_SCALE;
-    const float A22 = (float)uniform_i64(wave_sum_i64(a22)) * FLT_SCALE;
+    const float A11 = wave_sum_exact_f32(a11) * FLT_SCALE;
+    const float A12 = wave_sum_exact_f32(a12) * FLT_SCALE;
+    const float A22 = wave_sum_exact_f32(a22) * FLT_SCALE;
     float D = A11 * A22 - A12 * A12;
     const float minEig =
         (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
@@ -275,38 +371,34 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         if (level == 0) status = false;
         break;
       }
-      if (!staged || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + L.j_side ||
-          iny + win + 1 > jy0 + L.j_side) {
+      if (!staged || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + L.j_pitch || iny + win + 1 > jy0 + L.j_rows) {
         __syncthreads();  // previous iteration's reads are done
-        jx0 = inx - prm.jmargin;
+        jx0 = (inx - prm.jmargin) & ~3;
         jy0 = iny - prm.jmargin;
-        for (int i = lane; i < L.j_side * L.j_side; i += 64) {
-          const int y = i / L.j_side, x = i - y * L.j_side;
-          const int gy = reflect101(jy0 + y, bh), gx = reflect101(jx0 + x, bw);
-          sJ[y * L.j_pitch + x] = Bb[(long long)gy * bp + gx];
-        }
+        stage_region(sJ, L.j_pitch, L.j_rows, L.j_ndw_log2, Bb, bp, bw, bh, jx0, jy0, lane);
         staged = true;
         __syncthreads();
       }
       bilinear_weights(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
       int b1 = 0, b2 = 0;
       {
-        const uint8_t* c0 = sJ + (r + iny - jy0) * L.j_pitch + (x0 + inx - jx0);
-        const uint8_t* c1 = c0 + L.j_pitch;
+        unsigned int R0[NA], R1[NA];
+        const uint8_t* row0 = sJ + (rr + iny - jy0) * L.j_pitch;
+        lds_stream<NA>(row0, xx0 + inx - jx0, R0);
+        lds_stream<NA>(row0 + L.j_pitch, xx0 + inx - jx0, R1);
+        const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
+        const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
+        int Jw[SEG];
+        BilinearRow<0, SEG, NA>::run(R0, R1, W0, W1, Jw);
 #pragma unroll
         for (int k = 0; k < SEG; k++) {
-          if (k < cnt) {
-            const int diff = VSF_DESCALE((int)c0[k] * iw00 + (int)c0[k + 1] * iw01 + (int)c1[k] * iw10 +
-                                             (int)c1[k + 1] * iw11,
-                                         W_BITS - 5) -
-                             Iw[k];
-            b1 += diff * Ixw[k];
-            b2 += diff * Iyw[k];
-          }
+          const int diff = VSF_DESCALE(Jw[k], W_BITS - 5) - Iw[k];
+          b1 += __mul24(diff, Ixw[k]);
+          b2 += __mul24(diff, Iyw[k]);
         }
       }
-      const float fb1 = (float)uniform_i64(wave_sum_i64(b1)) * FLT_SCALE;
-      const float fb2 = (float)uniform_i64(wave_sum_i64(b2)) * FLT_SCALE;
+      const float fb1 = wave_sum_exact_f32(b1) * FLT_SCALE;
+      const float fb2 = wave_sum_exact_f32(b2) * FLT_SCALE;
       const float dx = (A12 * fb2 - A22 * fb1) * D;
       const float dy = (A12 * fb1 - A11 * fb2) * D;
       cx += dx;
@@ -896,6 +988,39 @@ __global__ __launch_bounds__(256) void append_kernel(GridView G, const int* __re
     n[stream] = nn;
     max_feature_index[stream] = start + (uint64_t)K - 1ull;  // :238 feature_index - 1 (wraps)
   }
+}
+
+// Fixed-size track records for the end-of-step collective over xGMI: 24 bytes,
+// padded to the table capacity so every rank contributes the same byte count.
+struct TrackRecord {
+  uint64_t id;
+  float x, y;
+  uint32_t age;
+  uint32_t valid;
+};
+
+__global__ __launch_bounds__(256) void export_kernel(const uint64_t* __restrict__ ids,
+                                                     const double2* __restrict__ xy,
+                                                     const uint32_t* __restrict__ age, const int* __restrict__ n,
+                                                     int cap, long long total, TrackRecord* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int stream = (int)(i / cap), k = (int)(i - (long long)stream * cap);
+  TrackRecord r;
+  if (k < n[stream]) {
+    const double2 p = xy[i];
+    r.id = ids[i];
+    r.x = (float)p.x;
+    r.y = (float)p.y;
+    r.age = age[i];
+    r.valid = 1u;
+  } else {
+    r.id = 0;
+    r.x = r.y = 0.f;
+    r.age = 0u;
+    r.valid = 0u;
+  }
+  out[i] = r;
 }
 
 }  // namespace vsf
