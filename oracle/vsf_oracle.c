@@ -142,6 +142,9 @@ static inline int lvl_D(const orc_level* L, const int16_t* d, int x, int y, int 
   return d[((size_t)y * L->w + x) * 2 + c];
 }
 
+/* debug statistics (not part of any result): iterations and level passes executed */
+long long orc_dbg_iters = 0, orc_dbg_level_passes = 0, orc_dbg_restage_moves = 0;
+
 static void lk_level(const orc_level* I, const int16_t* dI, const orc_level* J,
                      const float* prev_pts, float* next_pts, uint8_t* status, float* err, int n,
                      int win, int level, int max_level, int max_count, double epsilon,
@@ -226,8 +229,10 @@ static void lk_level(const orc_level* I, const int16_t* dI, const orc_level* J,
     nx -= half;
     ny -= half;
     float pdx = 0, pdy = 0;
+    orc_dbg_level_passes++;
     for (int j = 0; j < max_count; j++) {
       int inx = cv_floor_f(nx), iny = cv_floor_f(ny);
+      orc_dbg_iters++;
       if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
         if (level == 0) status[i] = 0;
         break;

@@ -40,6 +40,7 @@ struct vsf_ctx {
   // pyramid geometry
   int nlevels = 0;
   int lw[MAXL], lh[MAXL];
+  int lp[MAXL];  // pitch of levels >= 1 (width rounded up to 4 so rows stay dword aligned)
   // tracker state
   PyrSet track_pyr[2];
   FrameRef track_frame[2];
@@ -151,8 +152,8 @@ PyrView make_view(const vsf_ctx* c, const FrameRef& f, const PyrSet& ps) {
       v.pitch[0] = f.pitch;
     } else {
       v.base[l] = ps.lv[l];
-      v.sstride[l] = (long long)c->lw[l] * c->lh[l];
-      v.pitch[l] = c->lw[l];
+      v.sstride[l] = (long long)c->lp[l] * c->lh[l];
+      v.pitch[l] = c->lp[l];
     }
   }
   return v;
@@ -160,7 +161,7 @@ PyrView make_view(const vsf_ctx* c, const FrameRef& f, const PyrSet& ps) {
 
 int alloc_pyr(vsf_ctx* c, PyrSet* ps, int streams) {
   for (int l = 1; l < c->nlevels; l++) {
-    int rc = dalloc(c, &ps->lv[l], (size_t)streams * c->lw[l] * c->lh[l]);
+    int rc = dalloc(c, &ps->lv[l], (size_t)streams * c->lp[l] * c->lh[l] + 16);
     if (rc) return rc;
   }
   return VSF_OK;
@@ -171,11 +172,11 @@ int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStr
   ProfScope prof(c, VSF_K_PYRAMID, s);
   for (int l = 1; l < c->nlevels; l++) {
     const uint8_t* src = (l == 1) ? f.ptr : ps.lv[l - 1];
-    const long long sst = (l == 1) ? f.sstride : (long long)c->lw[l - 1] * c->lh[l - 1];
-    const int sp = (l == 1) ? f.pitch : c->lw[l - 1];
+    const long long sst = (l == 1) ? f.sstride : (long long)c->lp[l - 1] * c->lh[l - 1];
+    const int sp = (l == 1) ? f.pitch : c->lp[l - 1];
     dim3 grid((c->lw[l] + PD_TW - 1) / PD_TW, (c->lh[l] + PD_TH - 1) / PD_TH, streams);
     hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
-                       ps.lv[l], (long long)c->lw[l] * c->lh[l], c->lw[l], c->lw[l], c->lh[l]);
+                       ps.lv[l], (long long)c->lp[l] * c->lh[l], c->lp[l], c->lw[l], c->lh[l]);
   }
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
@@ -444,6 +445,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     for (;; l++) {
       c->lw[l] = w;
       c->lh[l] = h;
+      c->lp[l] = (w + 3) & ~3;
       w = (w + 1) / 2;
       h = (h + 1) / 2;
       if (l == p->klt_max_level || w <= p->klt_win || h <= p->klt_win) break;
@@ -783,7 +785,8 @@ int vsf_debug_pyramid(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
   HIPCHK(c, hipStreamSynchronize(nullptr));
   for (int l = 1; l < c->nlevels; l++)
     if (out_levels[l])
-      HIPCHK(c, hipMemcpy(out_levels[l], c->pair_pyr[0].lv[l], (size_t)c->lw[l] * c->lh[l], hipMemcpyDeviceToHost));
+      HIPCHK(c, hipMemcpy2D(out_levels[l], (size_t)c->lw[l], c->pair_pyr[0].lv[l], (size_t)c->lp[l], (size_t)c->lw[l],
+                            (size_t)c->lh[l], hipMemcpyDeviceToHost));
   *max_level_out = c->nlevels - 1;
   return VSF_OK;
 }

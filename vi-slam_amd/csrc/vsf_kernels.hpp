@@ -122,6 +122,33 @@ __device__ __forceinline__ float wave_sum_exact_f32(int p) {
   const int shi = wave_sum_i32(p >> 16);
   return (float)((double)shi * 65536.0 + (double)slo);
 }
+// The same for N values at once, with the DPP steps of the 2N limb chains interleaved so that no
+// chain waits on its own previous step.
+template <int N>
+__device__ __forceinline__ void wave_sums_exact_f32(const int (&p)[N], float (&out)[N]) {
+  int v[2 * N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    v[2 * i] = p[i] & 0xffff;
+    v[2 * i + 1] = p[i] >> 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x4E, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x141, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x140, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const int slo = __builtin_amdgcn_readlane(v[2 * i], 0) + __builtin_amdgcn_readlane(v[2 * i], 16) +
+                    __builtin_amdgcn_readlane(v[2 * i], 32) + __builtin_amdgcn_readlane(v[2 * i], 48);
+    const int shi = __builtin_amdgcn_readlane(v[2 * i + 1], 0) + __builtin_amdgcn_readlane(v[2 * i + 1], 16) +
+                    __builtin_amdgcn_readlane(v[2 * i + 1], 32) + __builtin_amdgcn_readlane(v[2 * i + 1], 48);
+    out[i] = (float)((double)shi * 65536.0 + (double)slo);
+  }
+}
 
 __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
   w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
@@ -164,75 +191,105 @@ __device__ __forceinline__ unsigned int byte_pair(const unsigned int (&A)[NA]) {
   }
 }
 
-template <int K, int SEG, int NA>
+template <int K, int N, int NA, int C0>
 struct BilinearRow {
-  // out[k] = sum over the 2x2 neighbourhood, for k = K..SEG-1 (compile-time recursion keeps every
-  // index a constant, so the arrays stay in registers)
+  // out[k] = C0 + sum over the 2x2 neighbourhood, for k = K..N-1 (compile-time recursion keeps every
+  // index a constant, so the arrays stay in registers).  C0 carries DESCALE's rounding constant.
   static __device__ __forceinline__ void run(const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
-                                             unsigned int W0, unsigned int W1, int (&out)[SEG]) {
-    out[K] = sdot2(byte_pair<K, NA>(A1), W1, sdot2(byte_pair<K, NA>(A0), W0, 0));
-    if constexpr (K + 1 < SEG) BilinearRow<K + 1, SEG, NA>::run(A0, A1, W0, W1, out);
+                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
+    out[K] = sdot2(byte_pair<K, NA>(A1), W1, sdot2(byte_pair<K, NA>(A0), W0, C0));
+    if constexpr (K + 1 < N) BilinearRow<K + 1, N, NA, C0>::run(A0, A1, W0, W1, out);
   }
 };
 
-// LDS carve-up per wave (bytes)
-struct LkSmem {
-  int i_pitch, i_rows, i_ndw_log2;  // template patch of I: rows = win+3
-  int d_pitch;                      // gradient patch (win+1)^2, packed (Ix | Iy<<16) int32
-  int j_pitch, j_rows, j_ndw_log2;  // staged J region
-  int off_d, off_j, total;
+// LDS carve-up per wave and the geometry of the two staged regions
+struct RegionGeom {
+  int ndw;    // staged dwords per row
+  int inv;    // ceil(2^16 / ndw): (t * inv) >> 16 == t / ndw for every task index used
+  int rows;   // staged rows
+  int pitch;  // LDS bytes per row: 4 * (ndw | 1), odd in dwords so that window rows hit distinct banks
 };
 
-__host__ __device__ inline int vsf_log2_ceil(int v) {
-  int l = 0;
-  while ((1 << l) < v) l++;
-  return l;
+struct LkSmem {
+  RegionGeom gi;  // template patch of I: (win+3) rows, covers win+3 columns at any 4-byte phase
+  RegionGeom gj;  // J region: window + margin
+  int d_pitch;    // gradient patch (win+1)^2, packed (Ix | Iy<<16) int32 (generic path only)
+  int off_j, off_d, total;
+};
+
+__host__ __device__ inline RegionGeom vsf_region_geom(int cols_needed, int rows) {
+  RegionGeom g;
+  g.ndw = (cols_needed + 3 + 3) / 4;  // any 4-byte phase of the origin
+  g.inv = (65536 + g.ndw - 1) / g.ndw;
+  g.rows = rows;
+  g.pitch = 4 * (g.ndw | 1);
+  return g;
 }
 
 __host__ __device__ inline LkSmem lk_smem_layout(int win, int jmargin) {
   LkSmem s;
-  s.i_pitch = ((win + 9) / 4) * 4;  // covers (win+3) columns at any 4-byte phase of the origin
-  s.i_rows = win + 3;
-  s.i_ndw_log2 = vsf_log2_ceil(s.i_pitch / 4);
+  s.gi = vsf_region_geom(win + 3, win + 3);
+  s.gj = vsf_region_geom(win + 1 + 2 * jmargin, win + 1 + 2 * jmargin);
   s.d_pitch = win + 1;
-  s.j_pitch = ((win + 1 + 2 * jmargin + 3 + 3) / 4) * 4;
-  s.j_rows = win + 1 + 2 * jmargin;
-  s.j_ndw_log2 = vsf_log2_ceil(s.j_pitch / 4);
-  const int si = s.i_pitch * s.i_rows + 32;  // +slack: dword-granular readers may run past a row end
-  s.off_d = (si + 15) & ~15;
-  s.off_j = s.off_d + ((s.d_pitch * (win + 1) * 4 + 15) & ~15);
-  s.total = s.off_j + ((s.j_pitch * s.j_rows + 32 + 15) & ~15);
+  const int si = s.gi.pitch * s.gi.rows + 32;  // +slack: dword-granular readers may run past a row end
+  s.off_j = (si + 15) & ~15;
+  s.off_d = s.off_j + ((s.gj.pitch * s.gj.rows + 32 + 15) & ~15);
+  s.total = s.off_d + ((s.d_pitch * (win + 1) * 4 + 15) & ~15);
   return s;
 }
 
-// Stages rows [y0, y0+rows) x byte columns [xa, xa+pitch) (xa a multiple of 4) of a level into LDS.
-// Interior regions are fetched as aligned dwords; regions touching the border go byte by byte with
-// REFLECT_101 indexing (values identical to OpenCV's reflect-padded pyramid level).
-__device__ __forceinline__ void stage_region(uint8_t* dst, int pitch, int rows, int ndw_log2,
-                                             const uint8_t* __restrict__ src, int sp, int sw, int sh, int xa,
-                                             int y0, int lane) {
-  const int ndw = pitch >> 2;
-  const int xd = lane & ((1 << ndw_log2) - 1), yl = lane >> ndw_log2, ystep = 64 >> ndw_log2;
-  const bool interior = xa >= 0 && y0 >= 0 && xa + pitch <= sw && y0 + rows <= sh && (sp & 3) == 0 &&
-                        ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
-  if (interior) {
-    if (xd < ndw) {
-      const unsigned int* s = reinterpret_cast<const unsigned int*>(src + (long long)y0 * sp + xa) + xd;
-      unsigned int* d = reinterpret_cast<unsigned int*>(dst) + xd;
-      const int spw = sp >> 2;
-      for (int y = yl; y < rows; y += ystep) d[y * ndw] = s[(long long)y * spw];
-    }
-  } else {
-    if (xd < ndw) {
-      int gx[4];
+// A region [xa, xa + 4*ndw) x [y0, y0 + rows) can be fetched as aligned dwords when it lies inside
+// the level and rows are dword aligned; otherwise it is assembled byte by byte with REFLECT_101.
+__device__ __forceinline__ bool region_is_fast(const uint8_t* src, int sp, int sw, int sh, int xa, int y0,
+                                               const RegionGeom& g) {
+  return xa >= 0 && y0 >= 0 && xa + 4 * g.ndw <= sw && y0 + g.rows <= sh && (sp & 3) == 0 &&
+         ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+}
+
+// Issues the aligned dword loads of a fast region into registers (no wait): task t = lane + 64*i
+// covers row t / ndw, dword t % ndw.
+template <int N>
+__device__ __forceinline__ void region_load_regs(unsigned int (&reg)[N], const uint8_t* __restrict__ src, int sp,
+                                                 int xa, int y0, const RegionGeom& g, int lane) {
+  const unsigned int* s = reinterpret_cast<const unsigned int*>(src + (long long)y0 * sp + xa);
+  const int spw = sp >> 2;
 #pragma unroll
-      for (int b = 0; b < 4; b++) gx[b] = reflect101(xa + 4 * xd + b, sw);
-      unsigned int* d = reinterpret_cast<unsigned int*>(dst) + xd;
-      for (int y = yl; y < rows; y += ystep) {
-        const uint8_t* sr = src + (long long)reflect101(y0 + y, sh) * sp;
-        d[y * ndw] = (unsigned int)sr[gx[0]] | ((unsigned int)sr[gx[1]] << 8) | ((unsigned int)sr[gx[2]] << 16) |
-                     ((unsigned int)sr[gx[3]] << 24);
-      }
+  for (int i = 0; i < N; i++) {
+    const int t = lane + 64 * i;
+    const int y = (t * g.inv) >> 16, xd = t - y * g.ndw;
+    reg[i] = 0u;
+    if (y < g.rows) reg[i] = s[(long long)y * spw + xd];
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void region_store_regs(uint8_t* dst, const unsigned int (&reg)[N], const RegionGeom& g,
+                                                  int lane) {
+  unsigned int* d = reinterpret_cast<unsigned int*>(dst);
+  const int pw = g.pitch >> 2;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const int t = lane + 64 * i;
+    const int y = (t * g.inv) >> 16, xd = t - y * g.ndw;
+    if (y < g.rows) d[y * pw + xd] = reg[i];
+  }
+}
+
+// Border path: values identical to OpenCV's reflect-padded pyramid level.
+template <int N>
+__device__ __forceinline__ void region_stage_slow(uint8_t* dst, const uint8_t* __restrict__ src, int sp, int sw,
+                                                  int sh, int xa, int y0, const RegionGeom& g, int lane) {
+  unsigned int* d = reinterpret_cast<unsigned int*>(dst);
+  const int pw = g.pitch >> 2;
+  for (int i = 0; i < N; i++) {
+    const int t = lane + 64 * i;
+    const int y = (t * g.inv) >> 16, xd = t - y * g.ndw;
+    if (y < g.rows) {
+      const uint8_t* sr = src + (long long)reflect101(y0 + y, sh) * sp;
+      unsigned int v = 0u;
+#pragma unroll
+      for (int b = 0; b < 4; b++) v |= (unsigned int)sr[reflect101(xa + 4 * xd + b, sw)] << (8 * b);
+      d[y * pw + xd] = v;
     }
   }
 }
@@ -243,7 +300,9 @@ template <int SEG>
 __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, float ptx, float pty,
                                float& outx, float& outy, const LkParams& prm, uint8_t* smem,
                                const LkSmem& L) {
-  constexpr int NA = (SEG + 1 + 3) / 4;  // aligned dwords holding SEG+1 bytes
+  constexpr int NA = (SEG + 1 + 3) / 4;     // aligned dwords holding SEG+1 bytes
+  constexpr int NI = (SEG <= 8) ? 3 : 6;    // I-patch dwords per lane (win <= 21 / <= 31)
+  constexpr int NJ = (SEG <= 8) ? 4 : 7;    // J-region dwords per lane (jmargin 3)
   const int lane = threadIdx.x & 63;
   const int win = prm.win;
   const int r = lane / prm.nseg;
@@ -252,13 +311,15 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
   const int cnt = owner ? min(prm.seglen, win - x0) : 0;
   const int rr = owner ? r : 0, xx0 = owner ? x0 : 0;        // idle lanes read a valid (unused) place
   uint8_t* sI = smem;
-  int* sD = reinterpret_cast<int*>(smem + L.off_d);
   uint8_t* sJ = smem + L.off_j;
+  int* sD = reinterpret_cast<int*>(smem + L.off_d);
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
   const int maxLevel = A.nlevels - 1;
   bool status = true;
   float nx = 0.f, ny = 0.f;  // nextPts
+
+  int jx0 = 0, jy0 = 0;
 
   for (int level = maxLevel; level >= 0; level--) {
     const float lscale = 1.f / (float)(1 << level);
@@ -274,153 +335,217 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     py -= half;
     const int ipx = (int)floorf(px), ipy = (int)floorf(py);
     const int aw = A.w[level], ah = A.h[level];
-    if (ipx < -win || ipx >= aw || ipy < -win || ipy >= ah) {
-      if (level == 0) status = false;
-      continue;
-    }
-    int iw00, iw01, iw10, iw11;
-    bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
-
-    // ---- stage the (win+3)-row patch of I; its column origin xaI is (ipx-1) rounded down to 4
+    const bool in_range = !(ipx < -win || ipx >= aw || ipy < -win || ipy >= ah);
     const int xaI = (ipx - 1) & ~3;
     const int oI = (ipx - 1) - xaI;
-    stage_region(sI, L.i_pitch, L.i_rows, L.i_ndw_log2, A.base[level] + (long long)stream * A.sstride[level],
-                 A.pitch[level], aw, ah, xaI, ipy - 1, lane);
-    __syncthreads();
-    // ---- Scharr gradient patch (win+1)^2, zero outside the level image (BORDER_CONSTANT)
-    {
-      const int side = win + 1;
-      const int xs = lane & 31;
-      if (xs < side) {
-        const int gx = ipx + xs;
-        const bool xin = gx >= 0 && gx < aw;
-        for (int y = lane >> 5; y < side; y += 2) {
-          const int gy = ipy + y;
-          int packed = 0;
-          if (xin && gy >= 0 && gy < ah) {
-            const uint8_t* c = sI + (y + 1) * L.i_pitch + (oI + xs + 1);
-            const int p = L.i_pitch;
-            const int i00 = c[-p - 1], i01 = c[-p], i02 = c[-p + 1];
-            const int i10 = c[-1], i12 = c[1];
-            const int i20 = c[p - 1], i21 = c[p], i22 = c[p + 1];
-            const int ix = 3 * (i02 - i00) + 10 * (i12 - i10) + 3 * (i22 - i20);
-            const int iy = 3 * (i20 - i00) + 10 * (i21 - i01) + 3 * (i22 - i02);
-            packed = (ix & 0xffff) | (iy << 16);
-          }
-          sD[y * L.d_pitch + xs] = packed;
-        }
-      }
-    }
-    __syncthreads();
-    // ---- per-lane template (registers) and the normal matrix
-    int Iw[SEG], Ixw[SEG], Iyw[SEG];
-    int a11 = 0, a12 = 0, a22 = 0;
-    {
-      unsigned int R0[NA], R1[NA];
-      lds_stream<NA>(sI + (rr + 1) * L.i_pitch, oI + 1 + xx0, R0);
-      lds_stream<NA>(sI + (rr + 2) * L.i_pitch, oI + 1 + xx0, R1);
-      const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
-      const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
-      BilinearRow<0, SEG, NA>::run(R0, R1, W0, W1, Iw);
-      const int* d0 = sD + rr * L.d_pitch + xx0;
-      const int* d1 = d0 + L.d_pitch;
-#pragma unroll
-      for (int k = 0; k < SEG; k++) {
-        Iw[k] = VSF_DESCALE(Iw[k], W_BITS - 5);
-        int ixval = 0, iyval = 0;
-        if (k < cnt) {
-          const int p00 = d0[k], p01 = d0[k + 1], p10 = d1[k], p11 = d1[k + 1];
-          ixval = VSF_DESCALE(__mul24((int)(short)(p00 & 0xffff), iw00) + __mul24((int)(short)(p01 & 0xffff), iw01) +
-                                  __mul24((int)(short)(p10 & 0xffff), iw10) +
-                                  __mul24((int)(short)(p11 & 0xffff), iw11),
-                              W_BITS);
-          iyval = VSF_DESCALE(__mul24(p00 >> 16, iw00) + __mul24(p01 >> 16, iw01) + __mul24(p10 >> 16, iw10) +
-                                  __mul24(p11 >> 16, iw11),
-                              W_BITS);
-        }
-        // pixels a lane does not own carry zero gradients, so they add nothing to any sum
-        Ixw[k] = ixval;
-        Iyw[k] = iyval;
-        a11 += __mul24(ixval, ixval);
-        a12 += __mul24(ixval, iyval);
-        a22 += __mul24(iyval, iyval);
-      }
-    }
-    const float A11 = wave_sum_exact_f32(a11) * FLT_SCALE;
-    const float A12 = wave_sum_exact_f32(a12) * FLT_SCALE;
-    const float A22 = wave_sum_exact_f32(a22) * FLT_SCALE;
-    float D = A11 * A22 - A12 * A12;
-    const float minEig =
-        (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
-    if ((double)minEig < prm.min_eig_thr || D < 1.1920928955078125e-7f) {
-      if (level == 0) status = false;
-      continue;
-    }
-    D = 1.f / D;
 
-    // ---- iterations
+    // ---- this level's I patch: aligned dwords when interior, assembled byte-wise at the border
+    if (in_range) {
+      const uint8_t* Ab = A.base[level] + (long long)stream * A.sstride[level];
+      if (region_is_fast(Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi)) {
+        unsigned int ri[NI];
+        region_load_regs<NI>(ri, Ab, A.pitch[level], xaI, ipy - 1, L.gi, lane);
+        region_store_regs<NI>(sI, ri, L.gi, lane);
+      } else {
+        region_stage_slow<NI>(sI, Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi, lane);
+      }
+    }
+    __syncthreads();
+
     const uint8_t* Bb = B.base[level] + (long long)stream * B.sstride[level];
     const int bp = B.pitch[level], bw = B.w[level], bh = B.h[level];
-    float cx = nx - half, cy = ny - half;  // nextPt - halfWin
-    float pdx = 0.f, pdy = 0.f;
-    int jx0 = 0, jy0 = 0;
-    bool staged = false;
-    for (int j = 0; j < prm.max_count; j++) {
-      const int inx = (int)floorf(cx), iny = (int)floorf(cy);
-      if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
-        if (level == 0) status = false;
-        break;
-      }
-      if (!staged || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + L.j_pitch || iny + win + 1 > jy0 + L.j_rows) {
-        __syncthreads();  // previous iteration's reads are done
-        jx0 = (inx - prm.jmargin) & ~3;
-        jy0 = iny - prm.jmargin;
-        stage_region(sJ, L.j_pitch, L.j_rows, L.j_ndw_log2, Bb, bp, bw, bh, jx0, jy0, lane);
-        staged = true;
-        __syncthreads();
-      }
-      bilinear_weights(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
-      int b1 = 0, b2 = 0;
-      {
-        unsigned int R0[NA], R1[NA];
-        const uint8_t* row0 = sJ + (rr + iny - jy0) * L.j_pitch;
-        lds_stream<NA>(row0, xx0 + inx - jx0, R0);
-        lds_stream<NA>(row0 + L.j_pitch, xx0 + inx - jx0, R1);
-        const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
-        const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
-        int Jw[SEG];
-        BilinearRow<0, SEG, NA>::run(R0, R1, W0, W1, Jw);
+    bool level_ok = in_range;
+    if (!in_range && level == 0) status = false;
+
+    int Iw[SEG], IxIy[SEG];  // template: I value, and (Ix & 0xffff) | (Iy << 16)
+    float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
+    if (level_ok) {
+      int iw00, iw01, iw10, iw11;
+      bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
+      const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
+      const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
+      int a11 = 0, a12 = 0, a22 = 0;
+      // every tap of every window pixel lies inside the level image: no zero-padded gradient involved
+      const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < aw && ipy + win < ah;
+      if (interior) {
+        // Fast path.  The Scharr operator and the bilinear interpolation are both linear and integer,
+        // so sum_w(w * Scharr(I)) == Scharr(V) with V = sum_w(w * I) (22 bits) evaluated on the window
+        // grid plus a one-pixel ring.  Each lane forms V on 3 rows x (SEG+2) columns from 4 patch
+        // rows, then applies the separable Scharr stencil; nothing goes through LDS again.
+        constexpr int NC = SEG + 2;            // V columns: window columns xx0-1 .. xx0+SEG
+        constexpr int NAV = (NC + 1 + 3) / 4;  // aligned dwords holding NC+1 bytes
+        unsigned int R0[NAV], R1[NAV], R2[NAV], R3[NAV];
+        lds_stream<NAV>(sI + (rr + 0) * L.gi.pitch, oI + xx0, R0);
+        lds_stream<NAV>(sI + (rr + 1) * L.gi.pitch, oI + xx0, R1);
+        lds_stream<NAV>(sI + (rr + 2) * L.gi.pitch, oI + xx0, R2);
+        lds_stream<NAV>(sI + (rr + 3) * L.gi.pitch, oI + xx0, R3);
+        int V0[NC], V1[NC], V2[NC];
+        BilinearRow<0, NC, NAV, 0>::run(R0, R1, W0, W1, V0);
+        BilinearRow<0, NC, NAV, 0>::run(R1, R2, W0, W1, V1);
+        BilinearRow<0, NC, NAV, 0>::run(R2, R3, W0, W1, V2);
+        int T0[NC], T1[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+          T0[c] = __mul24(V0[c] + V2[c], 3) + __mul24(V1[c], 10);  // < 2^27
+          T1[c] = V2[c] - V0[c];
+        }
 #pragma unroll
         for (int k = 0; k < SEG; k++) {
-          const int diff = VSF_DESCALE(Jw[k], W_BITS - 5) - Iw[k];
-          b1 += __mul24(diff, Ixw[k]);
-          b2 += __mul24(diff, Iyw[k]);
+          const bool own = k < cnt;
+          const int ixval = VSF_DESCALE(T0[k + 2] - T0[k], W_BITS);
+          const int iyval = VSF_DESCALE(3 * (T1[k] + T1[k + 2]) + 10 * T1[k + 1], W_BITS);
+          Iw[k] = VSF_DESCALE(V1[k + 1], W_BITS - 5);
+          // pixels a lane does not own carry zero gradients, so they add nothing to any sum
+          IxIy[k] = own ? ((ixval & 0xffff) | (iyval << 16)) : 0;
+        }
+      } else {
+        // Generic path (window touches the level border): Scharr gradient patch (win+1)^2 in LDS,
+        // zero outside the level image (BORDER_CONSTANT), then the bilinear template per lane.
+        {
+          const int side = win + 1;
+          const int xs = lane & 31;
+          if (xs < side) {
+            const int gx = ipx + xs;
+            const bool xin = gx >= 0 && gx < aw;
+            for (int y = lane >> 5; y < side; y += 2) {
+              const int gy = ipy + y;
+              int packed = 0;
+              if (xin && gy >= 0 && gy < ah) {
+                const uint8_t* c = sI + (y + 1) * L.gi.pitch + (oI + xs + 1);
+                const int p = L.gi.pitch;
+                const int i00 = c[-p - 1], i01 = c[-p], i02 = c[-p + 1];
+                const int i10 = c[-1], i12 = c[1];
+                const int i20 = c[p - 1], i21 = c[p], i22 = c[p + 1];
+                const int ix = 3 * (i02 - i00) + 10 * (i12 - i10) + 3 * (i22 - i20);
+                const int iy = 3 * (i20 - i00) + 10 * (i21 - i01) + 3 * (i22 - i02);
+                packed = (ix & 0xffff) | (iy << 16);
+              }
+              sD[y * L.d_pitch + xs] = packed;
+            }
+          }
+        }
+        __syncthreads();
+        unsigned int R0[NA], R1[NA];
+        lds_stream<NA>(sI + (rr + 1) * L.gi.pitch, oI + 1 + xx0, R0);
+        lds_stream<NA>(sI + (rr + 2) * L.gi.pitch, oI + 1 + xx0, R1);
+        BilinearRow<0, SEG, NA, (1 << (W_BITS - 5 - 1))>::run(R0, R1, W0, W1, Iw);
+        const int* d0 = sD + rr * L.d_pitch + xx0;
+        const int* d1 = d0 + L.d_pitch;
+#pragma unroll
+        for (int k = 0; k < SEG; k++) {
+          Iw[k] = Iw[k] >> (W_BITS - 5);
+          int ixval = 0, iyval = 0;
+          if (k < cnt) {
+            const int p00 = d0[k], p01 = d0[k + 1], p10 = d1[k], p11 = d1[k + 1];
+            ixval = VSF_DESCALE(__mul24((int)(short)(p00 & 0xffff), iw00) + __mul24((int)(short)(p01 & 0xffff), iw01) +
+                                    __mul24((int)(short)(p10 & 0xffff), iw10) +
+                                    __mul24((int)(short)(p11 & 0xffff), iw11),
+                                W_BITS);
+            iyval = VSF_DESCALE(__mul24(p00 >> 16, iw00) + __mul24(p01 >> 16, iw01) + __mul24(p10 >> 16, iw10) +
+                                    __mul24(p11 >> 16, iw11),
+                                W_BITS);
+          }
+          IxIy[k] = (ixval & 0xffff) | (iyval << 16);
         }
       }
-      const float fb1 = wave_sum_exact_f32(b1) * FLT_SCALE;
-      const float fb2 = wave_sum_exact_f32(b2) * FLT_SCALE;
-      const float dx = (A12 * fb2 - A22 * fb1) * D;
-      const float dy = (A12 * fb1 - A11 * fb2) * D;
-      cx += dx;
-      cy += dy;
-      nx = cx + half;
-      ny = cy + half;
-      if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
-      if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
-        nx -= dx * 0.5f;
-        ny -= dy * 0.5f;
-        break;
+#pragma unroll
+      for (int k = 0; k < SEG; k++) {
+        const int ix = (int)(short)(IxIy[k] & 0xffff), iy = IxIy[k] >> 16;
+        a11 += __mul24(ix, ix);
+        a12 += __mul24(ix, iy);
+        a22 += __mul24(iy, iy);
       }
-      pdx = dx;
-      pdy = dy;
+      float Asum[3];
+      {
+        const int part[3] = {a11, a12, a22};
+        wave_sums_exact_f32<3>(part, Asum);
+      }
+      A11 = Asum[0] * FLT_SCALE;
+      A12 = Asum[1] * FLT_SCALE;
+      A22 = Asum[2] * FLT_SCALE;
+      D = A11 * A22 - A12 * A12;
+      const float minEig =
+          (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+      if ((double)minEig < prm.min_eig_thr || D < 1.1920928955078125e-7f) {
+        if (level == 0) status = false;
+        level_ok = false;
+      }
+    }
+
+    if (level_ok) {
+      D = 1.f / D;
+      bool staged = false;
+      float cx = nx - half, cy = ny - half;  // nextPt - halfWin
+      float pdx = 0.f, pdy = 0.f;
+      for (int j = 0; j < prm.max_count; j++) {
+        const int inx = (int)floorf(cx), iny = (int)floorf(cy);
+        if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
+          if (level == 0) status = false;
+          break;
+        }
+        if (!staged || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + 4 * L.gj.ndw ||
+            iny + win + 1 > jy0 + L.gj.rows) {
+          __syncthreads();  // previous iteration's reads are done
+          jx0 = (inx - prm.jmargin) & ~3;
+          jy0 = iny - prm.jmargin;
+          if (region_is_fast(Bb, bp, bw, bh, jx0, jy0, L.gj)) {
+            unsigned int rj[NJ];
+            region_load_regs<NJ>(rj, Bb, bp, jx0, jy0, L.gj, lane);
+            region_store_regs<NJ>(sJ, rj, L.gj, lane);
+          } else {
+            region_stage_slow<NJ>(sJ, Bb, bp, bw, bh, jx0, jy0, L.gj, lane);
+          }
+          staged = true;
+          __syncthreads();
+        }
+        int iw00, iw01, iw10, iw11;
+        bilinear_weights(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
+        int b1 = 0, b2 = 0;
+        {
+          unsigned int R0[NA], R1[NA];
+          const uint8_t* row0 = sJ + (rr + iny - jy0) * L.gj.pitch;
+          lds_stream<NA>(row0, xx0 + inx - jx0, R0);
+          lds_stream<NA>(row0 + L.gj.pitch, xx0 + inx - jx0, R1);
+          const unsigned int V0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
+          const unsigned int V1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
+          int Jw[SEG];
+          BilinearRow<0, SEG, NA, (1 << (W_BITS - 5 - 1))>::run(R0, R1, V0, V1, Jw);
+#pragma unroll
+          for (int k = 0; k < SEG; k++) {
+            const int diff = (Jw[k] >> (W_BITS - 5)) - Iw[k];
+            b1 += __mul24(diff, (int)(short)(IxIy[k] & 0xffff));
+            b2 += __mul24(diff, IxIy[k] >> 16);
+          }
+        }
+        float bsum[2];
+        {
+          const int part[2] = {b1, b2};
+          wave_sums_exact_f32<2>(part, bsum);
+        }
+        const float fb1 = bsum[0] * FLT_SCALE, fb2 = bsum[1] * FLT_SCALE;
+        const float dx = (A12 * fb2 - A22 * fb1) * D;
+        const float dy = (A12 * fb1 - A11 * fb2) * D;
+        cx += dx;
+        cy += dy;
+        nx = cx + half;
+        ny = cy + half;
+        if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
+        if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+          nx -= dx * 0.5f;
+          ny -= dy * 0.5f;
+          break;
+        }
+        pdx = dx;
+        pdy = dy;
+      }
+      // cv: with err requested (the reference always passes an err vector) the final position is
+      // range-checked once more at level 0
+      if (status && level == 0) {
+        const int fx = (int)floorf(nx - half), fy = (int)floorf(ny - half);
+        if (fx < -win || fx >= bw || fy < -win || fy >= bh) status = false;
+      }
     }
     __syncthreads();  // LDS is reused by the next level
-    // cv: with err requested (the reference always passes an err vector) the final position is
-    // range-checked once more at level 0
-    if (status && level == 0) {
-      const int fx = (int)floorf(nx - half), fy = (int)floorf(ny - half);
-      if (fx < -win || fx >= bw || fy < -win || fy >= bh) status = false;
-    }
   }
   outx = nx;
   outy = ny;
