@@ -118,6 +118,8 @@ def main():
 
     from _pkg import load_package
     vsf = load_package()
+    import importlib
+    mg = importlib.import_module("vi_slam_amd.multigpu")
 
     B, T = args.streams, max(2, args.seq)
     frames = synth_frames(B, T, device, seed=rank)
@@ -132,7 +134,6 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     fstride = H * W
     records = torch.empty((B * cap * 24,), dtype=torch.uint8, device=device)
-    gathered = [torch.empty_like(records) for _ in range(world)] if world > 1 else None
 
     # ping-pong through the T resident frames so the motion stays continuous
     order = list(range(T)) + list(range(T - 2, 0, -1))
@@ -155,8 +156,7 @@ def main():
         ctx.batch_step(frame_ptr(step_i), fstride, W, stream)
         step_i += 1
     ctx.batch_export_tracks(records.data_ptr(), stream)
-    if dist is not None:
-        dist.all_gather(gathered, records)  # the only collective: RCCL gather of the track arrays
+    gathered = mg.gather_tracks(records, world, dist)  # the only collective: RCCL all_gather of track records
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

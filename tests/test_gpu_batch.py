@@ -1,0 +1,212 @@
+"""GPU parity of the batched device-resident API, the golden fixtures and the full-size configs
+(BASELINE.json C3 / C4), all through the C ABI."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL_PX = 0.01
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_golden_on_gpu(vsf, path):
+    g = np.load(path)
+    frames = g["frames"]
+    d, t = g["det_args"], g["trk_args"]
+    h, w = frames[0].shape
+    det = vsf.FeatureDetectorShiTomasiBucketing(int(d[0]), int(d[1]), int(d[2]), float(d[3]), w, h, capacity=256)
+    trk = vsf.FeatureTrackerLucasKanade(int(t[0]), float(t[1]), int(t[2]), int(t[3]), float(t[4]), w, h, capacity=256)
+    # building blocks
+    pyr = trk.ctx.debug_pyramid(frames[0])
+    for l, lv in enumerate(pyr):
+        assert np.array_equal(lv, g["pyr%d" % l])
+    got, rect = det.ctx.debug_min_eig(frames[0], 0)
+    assert np.array_equal(got.view(np.uint32), g["mineig_cell0"].view(np.uint32))
+    nxt, st = trk.ctx.debug_lk(frames[0], frames[1], g["lk_pts"])
+    assert np.array_equal(st, g["lk_status_exact"])
+    ok = st == 1
+    assert np.array_equal(nxt[ok].view(np.uint32), g["lk_next_exact"][ok].view(np.uint32))
+    assert np.array_equal(st, g["lk_status_seq"])
+    # frontend sequence, bit for bit against the exact-sum vectors
+    db = vsf.FeatureDatabase(256)
+    for k in range(len(frames)):
+        trk.Track(db, frames[k])
+        assert np.array_equal(db.ids[:db.n], g["exact_trk%d_ids" % k])
+        assert np.array_equal(db.xy[:db.n], g["exact_trk%d_xy" % k])
+        if k > 0:
+            assert tuple(trk.last_stats) == tuple(g["exact_trk%d_stats" % k])
+        # and within the north-star tolerance of the reference accumulation order
+        assert np.array_equal(db.ids[:db.n], g["seq_trk%d_ids" % k])
+        if db.n:
+            assert np.abs(db.xy[:db.n] - g["seq_trk%d_xy" % k]).max() <= TOL_PX
+        det.UpdateDetection(db, frames[k])
+        assert np.array_equal(db.ids[:db.n], g["exact_det%d_ids" % k])
+        assert np.array_equal(db.xy[:db.n], g["exact_det%d_xy" % k])
+        assert np.array_equal(db.age[:db.n], g["exact_det%d_age" % k])
+        assert det.max_feature_index_ == int(g["exact_det%d_maxidx" % k][0])
+
+
+def _oracle_streams(oracle, frames, det_args, trk_args, cap):
+    """frames: [T][B][H][W]; returns per-step list of per-stream dicts and the oracle objects."""
+    T, B = frames.shape[:2]
+    dets = [oracle.Detector(*det_args) for _ in range(B)]
+    trks = [oracle.Tracker(*trk_args, oracle.ACC_EXACT) for _ in range(B)]
+    tabs = [oracle.FeatureTable(cap) for _ in range(B)]
+    out = []
+    for t in range(T):
+        for b in range(B):
+            trks[b].track(tabs[b], frames[t, b])
+            dets[b].update_detection(tabs[b], frames[t, b])
+        out.append([tabs[b].as_dict() for b in range(B)])
+    return out, dets
+
+
+def test_batch_step_matches_per_stream_oracle(vsf, oracle, synth):
+    import importlib
+    import torch
+    mg = importlib.import_module("vi_slam_amd.multigpu")
+    w, h, B, T = 320, 240, 5, 4
+    seqs = [synth.sequence(700 + b, w, h, T)[0] for b in range(B)]
+    frames = np.stack(seqs, 1)                                    # [T][B][H][W]
+    det_args, trk_args = (2, 3, 120, 7.0), (30, 0.01, 21, 3, 1.0)
+    p = vsf.default_params(grid_rows=2, grid_cols=3, max_features=120, min_distance=7.0, klt_win=21, klt_max_level=3,
+                           width=w, height=h, streams=B, capacity=192)
+    ctx = vsf.Context(p)
+    dev = torch.from_numpy(frames).cuda()
+    exp, dets = _oracle_streams(oracle, frames, det_args, trk_args, 192)
+    records = torch.zeros(B * ctx.capacity * 24, dtype=torch.uint8, device="cuda")
+    for t in range(T):
+        ctx.batch_step(dev[t].data_ptr(), h * w, w, torch.cuda.current_stream().cuda_stream)
+        ids, xy, age, n, stats = ctx.batch_download()
+        for b in range(B):
+            got = {int(i): (float(q[0]), float(q[1]), int(a)) for i, q, a in zip(ids[b, :n[b]], xy[b, :n[b]], age[b, :n[b]])}
+            assert got == exp[t][b], "step %d stream %d" % (t, b)
+    assert (ctx.batch_status() == 0).all()
+    for b in range(B):
+        assert ctx.get_max_feature_index(b) == dets[b].max_feature_index
+    # packed 24-byte records for the collective
+    ctx.batch_export_tracks(records.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    allt = mg.unpack_tracks([records], 1, B, ctx.capacity)
+    for b in range(B):
+        e = exp[-1][b]
+        assert allt[b] == {i: (float(np.float32(v[0])), float(np.float32(v[1])), v[2]) for i, v in e.items()}
+    ctx.close()
+
+
+def test_batch_detect_with_masks_and_upload(vsf, oracle, synth):
+    import torch
+    w, h, B = 240, 160, 3
+    frames = np.stack([synth.sequence(800 + b, w, h, 1)[0][0] for b in range(B)])
+    masks = np.zeros((B, h, w), np.uint8)
+    masks[0, 20:140, 30:200] = 1
+    masks[1, :, :120] = 7
+    masks[2] = 1
+    p = vsf.default_params(grid_rows=2, grid_cols=2, max_features=80, min_distance=5.0, width=w, height=h, streams=B,
+                           capacity=128)
+    ctx = vsf.Context(p)
+    # pre-existing features (some outside the image) uploaded per stream
+    rng = np.random.default_rng(3)
+    ids = np.zeros((B, 128), np.uint64)
+    xy = np.zeros((B, 128, 2))
+    age = np.zeros((B, 128), np.uint32)
+    n = np.array([6, 0, 11], np.int32)
+    tabs = []
+    for b in range(B):
+        ids[b, :n[b]] = 5000 + np.arange(n[b])
+        xy[b, :n[b]] = np.stack([rng.uniform(-10, w + 10, n[b]), rng.uniform(-10, h + 10, n[b])], 1)
+        age[b, :n[b]] = 4
+        t = oracle.FeatureTable(128)
+        t.set(ids[b, :n[b]], xy[b, :n[b]], age[b, :n[b]])
+        tabs.append(t)
+    ctx.batch_upload(ids, xy, age, n)
+    df, dm = torch.from_numpy(frames).cuda(), torch.from_numpy(masks).cuda()
+    ctx.batch_detect(df.data_ptr(), h * w, w, dm.data_ptr(), h * w, w)
+    gi, gx, ga, gn, _ = ctx.batch_download()
+    for b in range(B):
+        d = oracle.Detector(2, 2, 80, 5.0)
+        assert d.update_detection(tabs[b], frames[b], masks[b]) == 0
+        got = {int(i): (float(q[0]), float(q[1]), int(a)) for i, q, a in zip(gi[b, :gn[b]], gx[b, :gn[b]], ga[b, :gn[b]])}
+        assert got == tabs[b].as_dict()
+    ctx.close()
+
+
+def _big_sequence(synth, w, h, seed, n):
+    """Full-size frames from a tiled scene (rendering 10^4 blobs directly would take minutes)."""
+    tw, th = 640 + 2 * synth.MARGIN, 360 + 2 * synth.MARGIN
+    tile = synth.make_scene(seed, 640, 360)
+    reps = ((h + 2 * synth.MARGIN + th - 1) // th, (w + 2 * synth.MARGIN + tw - 1) // tw)
+    scene = np.tile(tile, reps)[:h + 2 * synth.MARGIN, :w + 2 * synth.MARGIN]
+    rng = np.random.default_rng(seed)
+    scene = scene + rng.normal(0, 6.0, scene.shape).astype(np.float32)  # break the tile symmetry
+    mot = [(0.0, 0.0, 0.0), (1.7, -1.2, 0.05), (3.1, -2.9, 0.11)][:n]
+    return np.stack([synth.render(scene, w, h, *m, noise_seed=seed * 10 + i) for i, m in enumerate(mot)]), mot
+
+
+@pytest.mark.parametrize("name,w,h,levels,grid,maxn,mind", [
+    ("C3", 1280, 720, 4, (5, 8), 1000, 8.0),      # BASELINE.json configs[2]
+    ("C4", 3840, 2160, 5, (10, 16), 4000, 12.0),  # BASELINE.json configs[3]
+])
+def test_full_size_configs(vsf, oracle, synth, name, w, h, levels, grid, maxn, mind):
+    frames, mot = _big_sequence(synth, w, h, 11, 3)
+    cap = maxn + 256
+    det_args, trk_args = (grid[0], grid[1], maxn, mind), (30, 0.01, 21, levels - 1, 1.0)
+    det = vsf.FeatureDetectorShiTomasiBucketing(*det_args, w, h, capacity=cap)
+    trk = vsf.FeatureTrackerLucasKanade(*trk_args, w, h, capacity=cap)
+    db = vsf.FeatureDatabase(cap)
+    odet, otrk, otab = oracle.Detector(*det_args), oracle.Tracker(*trk_args, oracle.ACC_EXACT), oracle.FeatureTable(cap)
+    for k in range(3):
+        trk.Track(db, frames[k])
+        otrk.track(otab, frames[k])
+        assert db.as_dict() == otab.as_dict(), "%s track step %d" % (name, k)
+        if k > 0:
+            assert db.n > 0.8 * n_before            # smooth motion: most features survive
+        det.UpdateDetection(db, frames[k])
+        odet.update_detection(otab, frames[k])
+        assert db.as_dict() == otab.as_dict(), "%s detect step %d" % (name, k)
+        n_before = db.n
+        if k == 0:
+            first = db.as_dict()
+    # size-independent properties of the detector output (first call, empty table)
+    rects, _ = oracle.generate_grid(w, h, grid[1], grid[0])
+    capc = maxn // (grid[0] * grid[1])
+    pts = np.array([v[:2] for v in first.values()])
+    assert sorted(first) == list(range(len(first)))
+    per_cell = []
+    for (rx, ry, rw, rh) in rects:
+        inside = pts[(pts[:, 0] >= rx) & (pts[:, 0] < rx + rw) & (pts[:, 1] >= ry) & (pts[:, 1] < ry + rh)]
+        per_cell.append(len(inside))
+        assert len(inside) <= capc
+        if len(inside) > 1:
+            dd = np.linalg.norm(inside[:, None] - inside[None], axis=2) + np.eye(len(inside)) * 1e9
+            assert dd.min() >= mind
+        # the outermost ring of a cell never holds a corner
+        assert ((inside[:, 0] > rx) & (inside[:, 0] < rx + rw - 1) & (inside[:, 1] > ry) & (inside[:, 1] < ry + rh - 1)).all()
+    assert sum(per_cell) == len(first) and len(first) > 0.5 * maxn
+
+
+def test_identity_and_shift_properties_full_size(vsf, synth):
+    w, h = 1280, 720
+    frames, _ = _big_sequence(synth, w, h, 5, 1)
+    a = frames[0]
+    det = vsf.FeatureDetectorShiTomasiBucketing(5, 8, 1000, 8.0, w, h, capacity=1200)
+    trk = vsf.FeatureTrackerLucasKanade(30, 0.01, 21, 3, 1.0, w, h, capacity=1200)
+    db = vsf.FeatureDatabase(1200)
+    det.UpdateDetection(db, a)
+    before = db.as_dict()
+    trk.Track(db, a, a)                              # identical frames: nothing moves, nothing is lost
+    after = db.as_dict()
+    assert after.keys() == before.keys()
+    assert max(abs(after[i][0] - before[i][0]) + abs(after[i][1] - before[i][1]) for i in after) < 1e-3
+    b = np.roll(a, (3, -5), axis=(0, 1))             # b(x, y) = a(x + 5, y - 3): flow = (-5, +3)
+    db2 = vsf.FeatureDatabase(1200)
+    db2.set(db.ids[:db.n], db.xy[:db.n], db.age[:db.n])
+    trk.Track(db2, a, b)
+    moved = db2.as_dict()
+    inner = [i for i in moved if 40 < before[i][0] < w - 40 and 40 < before[i][1] < h - 40]
+    assert len(inner) > 300
+    err = max(max(abs(moved[i][0] - (before[i][0] - 5)), abs(moved[i][1] - (before[i][1] + 3))) for i in inner)
+    assert err < 0.05

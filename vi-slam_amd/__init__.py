@@ -62,6 +62,14 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("HIP extension missing: %s (run __graft_entry__.build())" % LIB_PATH)
+        # PyTorch wheels bundle their own libamdhip64.  Two HIP runtimes in one process leave the
+        # second one without devices, so when torch is installed let it bring its runtime in first
+        # (libvsf_hip.so then binds to that copy).  VSF_NO_TORCH=1 skips this for torch-free hosts.
+        if os.environ.get("VSF_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = C.CDLL(LIB_PATH)
         L.vsf_last_error.restype = C.c_char_p
         L.vsf_version.restype = C.c_char_p
