@@ -1,0 +1,51 @@
+// Drives the C++ mirror classes the way example/vslam/example_feature_detection_and_tracking.cpp:41-56
+// drives the reference: detect on the first frame, then Track (4-argument form) and a periodic
+// UpdateDetection.  Reads raw 8-bit frames, writes the databases after every frame as text; the
+// pytest wrapper (tests/test_gpu_cpp_mirror.py) compares them with the CPU oracle.
+//   usage: frontend_mirror_main frames.raw W H N out.txt rows cols maxN minDist iter eps win lvl back
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <vector>
+
+#include "vsf_frontend.hpp"
+
+int main(int argc, char** argv) {
+  if (argc != 15) {
+    std::fprintf(stderr, "bad arguments\n");
+    return 2;
+  }
+  const int W = std::atoi(argv[2]), H = std::atoi(argv[3]), N = std::atoi(argv[4]);
+  std::vector<uint8_t> buf((size_t)W * H * N);
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f || std::fread(buf.data(), 1, buf.size(), f) != buf.size()) return 3;
+  std::fclose(f);
+  try {
+    vslam::feature::FeatureDetectorShiTomasiBucketing shi_tomasi_detector(std::atoi(argv[6]), std::atoi(argv[7]),
+                                                                          std::atoi(argv[8]), std::atof(argv[9]));
+    vslam::feature::FeatureTrackerLucasKanade kl_tracker(std::atoi(argv[10]), std::atof(argv[11]), std::atoi(argv[12]),
+                                                         std::atoi(argv[13]), std::atof(argv[14]));
+    vslam::FeaturePositionDatabase prev_feature_position;
+    vslam::FeatureAgeDatabase prev_feature_age;
+    FILE* out = std::fopen(argv[5], "w");
+    for (int k = 0; k < N; k++) {
+      vslam::feature::ImageView frame(buf.data() + (size_t)k * W * H, W, H);
+      if (k == 0) {
+        shi_tomasi_detector.UpdateDetection(prev_feature_position, prev_feature_age, frame);
+      } else {
+        if (k % 2 == 0) shi_tomasi_detector.UpdateDetection(prev_feature_position, prev_feature_age, frame);
+        vslam::feature::ImageView prev(buf.data() + (size_t)(k - 1) * W * H, W, H);
+        kl_tracker.Track(prev_feature_position, prev_feature_age, prev, frame);
+      }
+      std::map<uint64_t, vslam::Vec2_t> sorted(prev_feature_position.begin(), prev_feature_position.end());
+      std::fprintf(out, "frame %d %zu %llu\n", k, sorted.size(), (unsigned long long)shi_tomasi_detector.max_feature_index());
+      for (const auto& [id, p] : sorted)
+        std::fprintf(out, "%llu %.17g %.17g %u\n", (unsigned long long)id, p[0], p[1], prev_feature_age[id]);
+    }
+    std::fclose(out);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "%s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

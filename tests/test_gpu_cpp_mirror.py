@@ -1,0 +1,43 @@
+"""The C++ host mirror (vi-slam_amd/host/vsf_frontend.hpp: same class names and call pattern as the
+reference's example_feature_detection_and_tracking.cpp) against the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "frontend_mirror_main")
+
+
+def test_mirror_binary_is_built():
+    assert os.path.exists(EXE), "run __graft_entry__.build()"
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_matches_oracle(oracle, synth, tmp_path):
+    w, h, n = 400, 300, 5
+    frames, _ = synth.sequence(77, w, h, n)
+    raw, out = str(tmp_path / "f.raw"), str(tmp_path / "o.txt")
+    frames.tofile(raw)
+    det_args, trk_args = (3, 3, 180, 5.0), (30, 0.01, 21, 3, 1.0)
+    subprocess.check_call([EXE, raw, str(w), str(h), str(n), out] + [str(v) for v in det_args + trk_args], timeout=120)
+    got, cur = [], None
+    for line in open(out):
+        p = line.split()
+        if p[0] == "frame":
+            cur = {"maxidx": int(p[3]), "tab": {}}
+            got.append(cur)
+        else:
+            cur["tab"][int(p[0])] = (float(p[1]), float(p[2]), int(p[3]))
+    det, trk, tab = oracle.Detector(*det_args), oracle.Tracker(*trk_args, oracle.ACC_EXACT), oracle.FeatureTable(512)
+    for k in range(n):
+        if k == 0:
+            det.update_detection(tab, frames[0])
+        else:
+            if k % 2 == 0:
+                det.update_detection(tab, frames[k])
+            trk.track_pair(tab, frames[k - 1], frames[k])
+        assert got[k]["tab"] == tab.as_dict(), "frame %d" % k
+        assert got[k]["maxidx"] == det.max_feature_index
+    assert len(got[-1]["tab"]) > 50
