@@ -99,8 +99,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1024, help="independent streams (frames per step) per GPU")
     ap.add_argument("--seq", type=int, default=6, help="distinct frames per stream held in HBM")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-streams", type=int, default=32)
-    ap.add_argument("--cpu-steps", type=int, default=12)
+    ap.add_argument("--cpu-streams", type=int, default=64)
+    ap.add_argument("--cpu-steps", type=int, default=100)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -184,13 +184,13 @@ int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStr
 
 int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hipStream_t s) {
   ProfScope prof(c, VSF_K_LK, s);
-  dim3 grid(c->cap, streams);
+  dim3 grid((unsigned)(8 * c->cap * ((streams + 7) / 8)));  // 8 XCD residue classes x streams x features
   if (c->lk.seglen <= 8)
-    hipLaunchKernelGGL(lk_fb_kernel<8>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, c->lk,
-                       c->d_fwd, c->d_flags);
+    hipLaunchKernelGGL(lk_fb_kernel<8>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, streams,
+                       c->lk, c->d_fwd, c->d_flags);
   else
-    hipLaunchKernelGGL(lk_fb_kernel<16>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, c->lk,
-                       c->d_fwd, c->d_flags);
+    hipLaunchKernelGGL(lk_fb_kernel<16>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, streams,
+                       c->lk, c->d_fwd, c->d_flags);
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
 }

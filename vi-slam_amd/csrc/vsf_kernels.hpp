@@ -557,11 +557,17 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
 // ||back - original||_2 <= threshold in double against the ORIGINAL double position).
 template <int SEG>
 __global__ __launch_bounds__(64) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
-                                                   const int* __restrict__ n, int cap, LkParams prm,
-                                                   float2* __restrict__ fwd, uint8_t* __restrict__ flags) {
+                                                   const int* __restrict__ n, int cap, int nstreams,
+                                                   LkParams prm, float2* __restrict__ fwd,
+                                                   uint8_t* __restrict__ flags) {
   extern __shared__ __align__(16) uint8_t smem[];
-  const int stream = blockIdx.y, f = blockIdx.x;
-  if (f >= n[stream]) return;
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so all
+  // features of one stream are given to ONE residue class: their overlapping window lines are then
+  // fetched into a single L2 instead of eight.  Placement is a speed matter only.
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int grp = local / cap;
+  const int stream = grp * 8 + xcd, f = local - grp * cap;
+  if (stream >= nstreams || f >= n[stream]) return;
   const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
   const double2 p0 = xy[(long long)stream * cap + f];
   const float p0x = (float)p0.x, p0y = (float)p0.y;  // :210 double -> float narrowing
