@@ -6,6 +6,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -82,6 +83,9 @@ struct vsf_ctx {
   // LK
   LkParams lk;
   LkSmem lks;
+  LkQuadSmem lkq;
+  int lk_ns = 0;          // slots per lane of the four-features-per-wave kernel (2, 4, 6 or 8)
+  bool lk_quad = false;   // VSF_LK_IMPL=quad selects the experimental four-features-per-wave kernel
   // profiling
   bool prof = false;
   std::vector<EvPair> ev_used;
@@ -184,6 +188,22 @@ int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStr
 
 int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hipStream_t s) {
   ProfScope prof(c, VSF_K_LK, s);
+  if (c->lk_quad) {
+    const int quads = (c->cap + 3) / 4;
+    dim3 grid((unsigned)(8 * quads * ((streams + 7) / 8)));
+#define VSF_LAUNCH_Q(NS)                                                                                          \
+  hipLaunchKernelGGL(lkq_fb_kernel<NS>, grid, dim3(64), c->lkq.total, s, P, C, c->d_xy, c->d_n, c->cap, quads, \
+                     streams, c->lk, c->d_fwd, c->d_flags)
+    switch (c->lk_ns) {
+      case 2: VSF_LAUNCH_Q(2); break;
+      case 4: VSF_LAUNCH_Q(4); break;
+      case 6: VSF_LAUNCH_Q(6); break;
+      default: VSF_LAUNCH_Q(8); break;
+    }
+#undef VSF_LAUNCH_Q
+    HIPCHK(c, hipGetLastError());
+    return VSF_OK;
+  }
   dim3 grid((unsigned)(8 * c->cap * ((streams + 7) / 8)));  // 8 XCD residue classes x streams x features
   if (c->lk.seglen <= 8)
     hipLaunchKernelGGL(lk_fb_kernel<8>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, streams,
@@ -467,7 +487,14 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     k.min_eig_thr = p->min_eig_thr;
     k.backtrack_thr = p->backtrack_thr;
     k.jmargin = 3;
+    k.q_nseg = (k.win + 7) / 8;
+    k.q_seglen = (k.win + k.q_nseg - 1) / k.q_nseg;
+    const int slots = (k.win * k.q_nseg + 15) / 16;
+    c->lk_ns = slots <= 2 ? 2 : slots <= 4 ? 4 : slots <= 6 ? 6 : 8;
     c->lks = lk_smem_layout(k.win, k.jmargin);
+    c->lkq = lkq_smem_layout(k.win, k.jmargin);
+    const char* impl = getenv("VSF_LK_IMPL");
+    c->lk_quad = impl && strcmp(impl, "quad") == 0;
   }
   // detector grid
   std::vector<int4> rects;
@@ -814,7 +841,18 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
   if (!rc) rc = build_pyramid(c, fc, c->pair_pyr[1], 1, nullptr);
   if (!rc) {
     const PyrView P = make_view(c, fp, c->pair_pyr[0]), C = make_view(c, fc, c->pair_pyr[1]);
-    if (c->lk.seglen <= 8)
+    if (c->lk_quad) {
+      dim3 grid((unsigned)((n + 3) / 4));
+#define VSF_LAUNCH_QP(NS) \
+  hipLaunchKernelGGL(lkq_points_kernel<NS>, grid, dim3(64), c->lkq.total, nullptr, P, C, d_in, n, c->lk, d_out, d_st)
+      switch (c->lk_ns) {
+        case 2: VSF_LAUNCH_QP(2); break;
+        case 4: VSF_LAUNCH_QP(4); break;
+        case 6: VSF_LAUNCH_QP(6); break;
+        default: VSF_LAUNCH_QP(8); break;
+      }
+#undef VSF_LAUNCH_QP
+    } else if (c->lk.seglen <= 8)
       hipLaunchKernelGGL(lk_points_kernel<8>, dim3(n), dim3(64), c->lks.total, nullptr, P, C, d_in, n, c->lk, d_out,
                          d_st);
     else

@@ -37,6 +37,8 @@ struct LkParams {
   double min_eig_thr;
   double backtrack_thr;
   int jmargin;    // extra margin staged around the J window
+  int q_nseg;     // four-features-per-wave variant: segments per window row (<= 8 pixels each)
+  int q_seglen;
 };
 
 // cv: borderInterpolate(p, len, BORDER_REFLECT_101), one reflection, then clamped for memory safety
@@ -605,6 +607,10 @@ __global__ __launch_bounds__(64) void lk_points_kernel(PyrView P, PyrView C, con
     status[f] = st ? 1 : 0;
   }
 }
+
+}  // namespace vsf
+#include "vsf_lk_quad.hpp"
+namespace vsf {
 
 // Stable in-place compaction of one stream's table by the verified flag; also the three counts
 // the reference logs (FeatureTrackerLucasKanade.cpp:87-104).  One block of 256 threads per stream.
