@@ -135,7 +135,8 @@ def test_detector_mask_and_quirks(vsf, oracle, synth):
 
 
 def test_lk_quad_variant_bit_exact(vsf, oracle, synth, monkeypatch):
-    """The experimental four-features-per-wave LK kernel (VSF_LK_IMPL=quad, vsf_lk_quad.hpp) computes
+    """The experimental several-features-per-wave LK kernel (VSF_LK_IMPL=quad, vsf_lk_quad.hpp; two
+    features of 32 lanes per wave as built) computes
     exactly what the default kernel computes."""
     monkeypatch.setenv("VSF_LK_IMPL", "quad")
     for (w, h, win, ml) in [(752, 480, 21, 3), (400, 300, 15, 3), (400, 300, 31, 2), (320, 240, 24, 3)]:

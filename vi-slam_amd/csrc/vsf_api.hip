@@ -84,7 +84,7 @@ struct vsf_ctx {
   LkParams lk;
   LkSmem lks;
   LkQuadSmem lkq;
-  int lk_ns = 0;          // slots per lane of the four-features-per-wave kernel (2, 4, 6 or 8)
+  int lk_ns = 0;          // slots per lane of the two-features-per-wave kernel (1..4)
   bool lk_quad = false;   // VSF_LK_IMPL=quad selects the experimental four-features-per-wave kernel
   // profiling
   bool prof = false;
@@ -189,16 +189,16 @@ int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStr
 int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hipStream_t s) {
   ProfScope prof(c, VSF_K_LK, s);
   if (c->lk_quad) {
-    const int quads = (c->cap + 3) / 4;
+    const int quads = (c->cap + 1) / 2;  // feature pairs per stream
     dim3 grid((unsigned)(8 * quads * ((streams + 7) / 8)));
-#define VSF_LAUNCH_Q(NS)                                                                                          \
-  hipLaunchKernelGGL(lkq_fb_kernel<NS>, grid, dim3(64), c->lkq.total, s, P, C, c->d_xy, c->d_n, c->cap, quads, \
+#define VSF_LAUNCH_Q(NS)                                                                                              \
+  hipLaunchKernelGGL((lkq_fb_kernel<NS, 32>), grid, dim3(64), c->lkq.total, s, P, C, c->d_xy, c->d_n, c->cap, quads, \
                      streams, c->lk, c->d_fwd, c->d_flags)
     switch (c->lk_ns) {
+      case 1: VSF_LAUNCH_Q(1); break;
       case 2: VSF_LAUNCH_Q(2); break;
-      case 4: VSF_LAUNCH_Q(4); break;
-      case 6: VSF_LAUNCH_Q(6); break;
-      default: VSF_LAUNCH_Q(8); break;
+      case 3: VSF_LAUNCH_Q(3); break;
+      default: VSF_LAUNCH_Q(4); break;
     }
 #undef VSF_LAUNCH_Q
     HIPCHK(c, hipGetLastError());
@@ -489,10 +489,9 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     k.jmargin = 3;
     k.q_nseg = (k.win + 7) / 8;
     k.q_seglen = (k.win + k.q_nseg - 1) / k.q_nseg;
-    const int slots = (k.win * k.q_nseg + 15) / 16;
-    c->lk_ns = slots <= 2 ? 2 : slots <= 4 ? 4 : slots <= 6 ? 6 : 8;
+    c->lk_ns = (k.win * k.q_nseg + 31) / 32;  // slots per lane with two features per wave (1..4)
     c->lks = lk_smem_layout(k.win, k.jmargin);
-    c->lkq = lkq_smem_layout(k.win, k.jmargin);
+    c->lkq = lkq_smem_layout(k.win, k.jmargin, 2);
     const char* impl = getenv("VSF_LK_IMPL");
     c->lk_quad = impl && strcmp(impl, "quad") == 0;
   }
@@ -842,14 +841,15 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
   if (!rc) {
     const PyrView P = make_view(c, fp, c->pair_pyr[0]), C = make_view(c, fc, c->pair_pyr[1]);
     if (c->lk_quad) {
-      dim3 grid((unsigned)((n + 3) / 4));
-#define VSF_LAUNCH_QP(NS) \
-  hipLaunchKernelGGL(lkq_points_kernel<NS>, grid, dim3(64), c->lkq.total, nullptr, P, C, d_in, n, c->lk, d_out, d_st)
+      dim3 grid((unsigned)((n + 1) / 2));
+#define VSF_LAUNCH_QP(NS)                                                                                        \
+  hipLaunchKernelGGL((lkq_points_kernel<NS, 32>), grid, dim3(64), c->lkq.total, nullptr, P, C, d_in, n, c->lk, \
+                     d_out, d_st)
       switch (c->lk_ns) {
+        case 1: VSF_LAUNCH_QP(1); break;
         case 2: VSF_LAUNCH_QP(2); break;
-        case 4: VSF_LAUNCH_QP(4); break;
-        case 6: VSF_LAUNCH_QP(6); break;
-        default: VSF_LAUNCH_QP(8); break;
+        case 3: VSF_LAUNCH_QP(3); break;
+        default: VSF_LAUNCH_QP(4); break;
       }
 #undef VSF_LAUNCH_QP
     } else if (c->lk.seglen <= 8)

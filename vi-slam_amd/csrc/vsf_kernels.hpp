@@ -124,20 +124,25 @@ __device__ __forceinline__ float wave_sum_exact_f32(int p) {
   const int shi = wave_sum_i32(p >> 16);
   return (float)((double)shi * 65536.0 + (double)slo);
 }
-// The same for N values at once, with the DPP steps of the 2N limb chains interleaved so that no
-// chain waits on its own previous step.
+// The same for N values at once.  Each |p| must be < 2^29 (true for every sum here: <= 16 pixels x
+// 8160 x 4080), so the first two DPP steps (sums over quads) still fit int32; only then is each value
+// split into the two limbs, which halves the DPP adds of those steps.  The limb chains are
+// interleaved so that no chain waits on its own previous step.  The recombination takes the int32
+// route (one v_cvt_f32_i32, exact round-to-nearest-even) whenever the total fits 32 bits and the
+// double route otherwise; both round the EXACT integer sum once.
 template <int N>
 __device__ __forceinline__ void wave_sums_exact_f32(const int (&p)[N], float (&out)[N]) {
+  int q[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = p[i] + __builtin_amdgcn_update_dpp(0, p[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] += __builtin_amdgcn_update_dpp(0, q[i], 0x4E, 0xf, 0xf, false);
   int v[2 * N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    v[2 * i] = p[i] & 0xffff;
-    v[2 * i + 1] = p[i] >> 16;
+    v[2 * i] = q[i] & 0xffff;
+    v[2 * i + 1] = q[i] >> 16;
   }
-#pragma unroll
-  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0xB1, 0xf, 0xf, false);
-#pragma unroll
-  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x4E, 0xf, 0xf, false);
 #pragma unroll
   for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x141, 0xf, 0xf, false);
 #pragma unroll
@@ -148,7 +153,11 @@ __device__ __forceinline__ void wave_sums_exact_f32(const int (&p)[N], float (&o
                     __builtin_amdgcn_readlane(v[2 * i], 32) + __builtin_amdgcn_readlane(v[2 * i], 48);
     const int shi = __builtin_amdgcn_readlane(v[2 * i + 1], 0) + __builtin_amdgcn_readlane(v[2 * i + 1], 16) +
                     __builtin_amdgcn_readlane(v[2 * i + 1], 32) + __builtin_amdgcn_readlane(v[2 * i + 1], 48);
-    out[i] = (float)((double)shi * 65536.0 + (double)slo);
+    // slo < 2^22 here, so shi in [-32768, 32766] keeps shi*65536 + slo inside int32
+    if (shi >= -32768 && shi <= 32766)
+      out[i] = (float)(shi * 65536 + slo);
+    else
+      out[i] = (float)((double)shi * 65536.0 + (double)slo);
   }
 }
 
@@ -203,6 +212,33 @@ struct BilinearRow {
     if constexpr (K + 1 < N) BilinearRow<K + 1, N, NA, C0>::run(A0, A1, W0, W1, out);
   }
 };
+
+typedef unsigned short vsf_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int udot2(unsigned int a, unsigned int b, int c) {
+  return (int)__builtin_amdgcn_udot2(__builtin_bit_cast(vsf_u16x2, a), __builtin_bit_cast(vsf_u16x2, b),
+                                     (unsigned int)c, false);
+}
+
+// Unsigned twin of BilinearRow for the common case of four non-negative weights: v_dot2_u32_u16 is a
+// three-operand instruction, so the accumulator constant needs no v_mov per pixel (the signed form
+// on gfx950 is the two-operand v_dot2c_i32_i16).
+template <int K, int N, int NA, int C0>
+struct BilinearRowU {
+  static __device__ __forceinline__ void run(const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
+                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
+    out[K] = udot2(byte_pair<K, NA>(A1), W1, udot2(byte_pair<K, NA>(A0), W0, C0));
+    if constexpr (K + 1 < N) BilinearRowU<K + 1, N, NA, C0>::run(A0, A1, W0, W1, out);
+  }
+};
+
+template <int N, int NA, int C0>
+__device__ __forceinline__ void bilinear_row(bool nonneg, const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
+                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
+  if (nonneg)
+    BilinearRowU<0, N, NA, C0>::run(A0, A1, W0, W1, out);
+  else
+    BilinearRow<0, N, NA, C0>::run(A0, A1, W0, W1, out);
+}
 
 // LDS carve-up per wave and the geometry of the two staged regions
 struct RegionGeom {
@@ -359,9 +395,11 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     bool level_ok = in_range;
     if (!in_range && level == 0) status = false;
 
-    int Iw[SEG], IxIy[SEG];  // template: I value, and (Ix & 0xffff) | (Iy << 16)
+    int IxIy[SEG];  // template gradients, (Ix & 0xffff) | (Iy << 16)
+    int cI1 = 0, cI2 = 0;
     float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
     if (level_ok) {
+      int Iw[SEG];
       int iw00, iw01, iw10, iw11;
       bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
       const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
@@ -382,9 +420,10 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         lds_stream<NAV>(sI + (rr + 2) * L.gi.pitch, oI + xx0, R2);
         lds_stream<NAV>(sI + (rr + 3) * L.gi.pitch, oI + xx0, R3);
         int V0[NC], V1[NC], V2[NC];
-        BilinearRow<0, NC, NAV, 0>::run(R0, R1, W0, W1, V0);
-        BilinearRow<0, NC, NAV, 0>::run(R1, R2, W0, W1, V1);
-        BilinearRow<0, NC, NAV, 0>::run(R2, R3, W0, W1, V2);
+        const bool wpos = iw11 >= 0;  // the other three weights are rounded products of non-negatives
+        bilinear_row<NC, NAV, 0>(wpos, R0, R1, W0, W1, V0);
+        bilinear_row<NC, NAV, 0>(wpos, R1, R2, W0, W1, V1);
+        bilinear_row<NC, NAV, 0>(wpos, R2, R3, W0, W1, V2);
         int T0[NC], T1[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++) {
@@ -450,12 +489,16 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           IxIy[k] = (ixval & 0xffff) | (iyval << 16);
         }
       }
+      // b = sum (Jw - Iw) * (Ix, Iy) = sum Jw * (Ix, Iy) - (cI1, cI2): the template's own part is a
+      // per-lane constant of the level, so the iterations neither subtract per pixel nor keep Iw live
 #pragma unroll
       for (int k = 0; k < SEG; k++) {
         const int ix = (int)(short)(IxIy[k] & 0xffff), iy = IxIy[k] >> 16;
         a11 += __mul24(ix, ix);
         a12 += __mul24(ix, iy);
         a22 += __mul24(iy, iy);
+        cI1 += __mul24(Iw[k], ix);
+        cI2 += __mul24(Iw[k], iy);
       }
       float Asum[3];
       {
@@ -502,7 +545,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         }
         int iw00, iw01, iw10, iw11;
         bilinear_weights(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
-        int b1 = 0, b2 = 0;
+        int b1 = -cI1, b2 = -cI2;
         {
           unsigned int R0[NA], R1[NA];
           const uint8_t* row0 = sJ + (rr + iny - jy0) * L.gj.pitch;
@@ -511,12 +554,12 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           const unsigned int V0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
           const unsigned int V1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
           int Jw[SEG];
-          BilinearRow<0, SEG, NA, (1 << (W_BITS - 5 - 1))>::run(R0, R1, V0, V1, Jw);
+          bilinear_row<SEG, NA, (1 << (W_BITS - 5 - 1))>(iw11 >= 0, R0, R1, V0, V1, Jw);
 #pragma unroll
           for (int k = 0; k < SEG; k++) {
-            const int diff = (Jw[k] >> (W_BITS - 5)) - Iw[k];
-            b1 += __mul24(diff, (int)(short)(IxIy[k] & 0xffff));
-            b2 += __mul24(diff, IxIy[k] >> 16);
+            const int jv = Jw[k] >> (W_BITS - 5);
+            b1 += __mul24(jv, (int)(short)(IxIy[k] & 0xffff));
+            b2 += __mul24(jv, IxIy[k] >> 16);
           }
         }
         float bsum[2];
@@ -532,7 +575,9 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         nx = cx + half;
         ny = cy + half;
         if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
-        if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+        // cv compares the float sums with the double 0.01; (float)0.01 is the largest float below
+        // 0.01, so `<= 0.01f` in float is the same predicate
+        if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
           nx -= dx * 0.5f;
           ny -= dy * 0.5f;
           break;

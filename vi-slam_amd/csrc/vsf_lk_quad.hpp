@@ -1,4 +1,5 @@
-// vsf_lk_quad.hpp -- pyramidal LK with FOUR features per wavefront (one 16-lane DPP row each).
+// vsf_lk_quad.hpp -- pyramidal LK with SEVERAL features per wavefront: G lanes per feature, G = 16
+// (four features, one DPP row each) or G = 32 (two features, two DPP rows each).
 //
 // Why: the wave-per-feature kernel is VALU-issue bound and ~70 % of its instructions are per-feature
 // "scalar" work (bilinear weights, 2x2 solve, convergence tests, reduction tails, addressing) that a
@@ -23,38 +24,46 @@ struct LkQuadSmem {
   int total;
 };
 
-__host__ __device__ inline LkQuadSmem lkq_smem_layout(int win, int jmargin) {
+__host__ __device__ inline LkQuadSmem lkq_smem_layout(int win, int jmargin, int groups) {
   LkQuadSmem s;
   s.gi = vsf_region_geom(win + 3, win + 3);
   s.gj = vsf_region_geom(win + 1 + 2 * jmargin, win + 1 + 2 * jmargin);
   s.d_pitch = win + 1;
   s.off_j = (s.gi.pitch * s.gi.rows + 32 + 15) & ~15;
   s.grp_bytes = s.off_j + ((s.gj.pitch * s.gj.rows + 32 + 15) & ~15);
-  s.off_d = 4 * s.grp_bytes;
+  s.off_d = groups * s.grp_bytes;
   s.total = s.off_d + ((s.d_pitch * (win + 1) * 4 + 15) & ~15);
   return s;
 }
 
-// float32(sum over the 16-lane row of p[i]), exact (see wave_sums_exact_f32); every lane of a row
-// receives its row's sums.  The 2N limb chains are interleaved.
-template <int N>
-__device__ __forceinline__ void row_sums_exact_f32(const int (&p)[N], float (&out)[N]) {
+// float32(sum over the G lanes of a feature of p[i]), exact; every lane of the group receives its
+// group's sums.  |p| < 2^29, so the two quad steps run on the raw value; then each value is split into
+// a 16-bit low limb and a signed high limb whose group sums fit int32 (DPP row steps, plus one
+// cross-row exchange for G = 32).  float(hi) * 65536 and float(lo) are both exact, so ONE fused
+// multiply-add rounds the exact integer sum to float32 once (= the oracle's (float)int64).
+template <int N, int G>
+__device__ __forceinline__ void group_sums_exact_f32(const int (&p)[N], float (&out)[N]) {
+  int q[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = p[i] + __builtin_amdgcn_update_dpp(0, p[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] += __builtin_amdgcn_update_dpp(0, q[i], 0x4E, 0xf, 0xf, false);
   int v[2 * N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    v[2 * i] = p[i] & 0xffff;
-    v[2 * i + 1] = p[i] >> 16;
+    v[2 * i] = q[i] & 0xffff;
+    v[2 * i + 1] = q[i] >> 16;
   }
-#pragma unroll
-  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0xB1, 0xf, 0xf, false);
-#pragma unroll
-  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x4E, 0xf, 0xf, false);
 #pragma unroll
   for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x141, 0xf, 0xf, false);
 #pragma unroll
   for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x140, 0xf, 0xf, false);
+  if constexpr (G == 32) {
 #pragma unroll
-  for (int i = 0; i < N; i++) out[i] = (float)((double)v[2 * i + 1] * 65536.0 + (double)v[2 * i]);
+    for (int i = 0; i < 2 * N; i++) v[i] += __shfl_xor(v[i], 16, 64);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) out[i] = __fmaf_rn((float)v[2 * i + 1], 65536.f, (float)v[2 * i]);
 }
 
 // Region staging by the 16 lanes of a row.  Lane gl takes dword column gl % cols (cols = 8 when the
@@ -62,11 +71,11 @@ __device__ __forceinline__ void row_sums_exact_f32(const int (&p)[N], float (&ou
 // loop in chunks of CH loads issued back to back (one exposed latency per chunk), and nothing about
 // the mapping is loop invariant enough to be hoisted into long-lived registers.
 // xa / y0 are per row (per feature); src is common to the wave (one stream per wave).
-template <int CH>
+template <int CH, int G>
 __device__ __forceinline__ void regionq_load_store(uint8_t* dst, const uint8_t* __restrict__ src, int sp, int xa,
                                                    int y0, const RegionGeom& g, int gl) {
   const int cl = g.ndw <= 8 ? 3 : 4;
-  const int xd = gl & ((1 << cl) - 1), yl = gl >> cl, ystep = 16 >> cl;
+  const int xd = gl & ((1 << cl) - 1), yl = gl >> cl, ystep = G >> cl;
   if (xd < g.ndw) {
     const unsigned int* s = reinterpret_cast<const unsigned int*>(src + (long long)y0 * sp + xa) + xd;
     unsigned int* d = reinterpret_cast<unsigned int*>(dst) + xd;
@@ -89,10 +98,11 @@ __device__ __forceinline__ void regionq_load_store(uint8_t* dst, const uint8_t* 
 }
 
 // Border path: values identical to OpenCV's reflect-padded pyramid level.
+template <int G>
 __device__ __forceinline__ void regionq_stage_slow(uint8_t* dst, const uint8_t* __restrict__ src, int sp, int sw,
                                                    int sh, int xa, int y0, const RegionGeom& g, int gl) {
   const int cl = g.ndw <= 8 ? 3 : 4;
-  const int xd = gl & ((1 << cl) - 1), yl = gl >> cl, ystep = 16 >> cl;
+  const int xd = gl & ((1 << cl) - 1), yl = gl >> cl, ystep = G >> cl;
   if (xd < g.ndw) {
     unsigned int* d = reinterpret_cast<unsigned int*>(dst) + xd;
     const int pw = g.pitch >> 2;
@@ -107,9 +117,9 @@ __device__ __forceinline__ void regionq_stage_slow(uint8_t* dst, const uint8_t* 
   }
 }
 
-// Tracks the four features of a wave (row g = lanes 16g..16g+15) from pyramid A to pyramid B.
-// `alive` : the row holds a feature.  Outputs are per lane (identical within a row).
-template <int NS>
+// Tracks the 64/G features of a wave (group g = lanes G*g .. G*g+G-1) from pyramid A to pyramid B.
+// `alive` : the group holds a feature.  Outputs are per lane (identical within a group).
+template <int NS, int G>
 __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool alive, float ptx, float pty,
                           float& outx, float& outy, bool& status_out, const LkParams& prm, uint8_t* smem,
                           const LkQuadSmem& L) {
@@ -117,7 +127,8 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
   constexpr int NA = (SEG + 1 + 3) / 4;
   constexpr int CH = 8;  // staging loads in flight per lane
   const int lane = threadIdx.x & 63;
-  const int g = lane >> 4, gl = lane & 15;
+  constexpr int F = 64 / G;  // features per wave
+  const int g = lane / G, gl = lane % G;
   const int win = prm.win;
   uint8_t* sI = smem + g * L.grp_bytes;
   uint8_t* sJ = sI + L.off_j;
@@ -130,7 +141,7 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
   int s_row[NS], s_x0[NS], s_cnt[NS];
 #pragma unroll
   for (int j = 0; j < NS; j++) {
-    const int q = gl + 16 * j;
+    const int q = gl + G * j;
     const int row = q / prm.q_nseg;
     const int x0 = (q - row * prm.q_nseg) * prm.q_seglen;
     const bool own = row < win && x0 < win;
@@ -170,9 +181,9 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
     // ---- I patch per row
     if (in_range) {
       if (region_is_fast(Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi))
-        regionq_load_store<CH>(sI, Ab, A.pitch[level], xaI, ipy - 1, L.gi, glv);
+        regionq_load_store<CH, G>(sI, Ab, A.pitch[level], xaI, ipy - 1, L.gi, glv);
       else
-        regionq_stage_slow(sI, Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi, glv);
+        regionq_stage_slow<G>(sI, Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi, glv);
     }
     __syncthreads();
     if (alive && !in_range && level == 0) status = false;
@@ -248,10 +259,10 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
       const unsigned long long gmask = __ballot(generic);
       if (gmask != 0ull) {
 #pragma unroll 1
-        for (int gg = 0; gg < 4; gg++) {
-          if ((gmask >> (16 * gg)) & 0xffffull) {
-            const int b_ipx = __builtin_amdgcn_readlane(ipx, 16 * gg), b_ipy = __builtin_amdgcn_readlane(ipy, 16 * gg);
-            const int b_oI = __builtin_amdgcn_readlane(oI, 16 * gg);
+        for (int gg = 0; gg < F; gg++) {
+          if ((gmask >> (G * gg)) & ((G == 32) ? 0xffffffffull : 0xffffull)) {
+            const int b_ipx = __builtin_amdgcn_readlane(ipx, G * gg), b_ipy = __builtin_amdgcn_readlane(ipy, G * gg);
+            const int b_oI = __builtin_amdgcn_readlane(oI, G * gg);
             const uint8_t* sIg = smem + gg * L.grp_bytes;
             const int side = win + 1;
             const int xs = lane & 31;
@@ -321,7 +332,7 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
     {
       float Asum[3];
       const int part[3] = {a11, a12, a22};
-      row_sums_exact_f32<3>(part, Asum);
+      group_sums_exact_f32<3, G>(part, Asum);
       A11 = Asum[0] * FLT_SCALE;
       A12 = Asum[1] * FLT_SCALE;
       A22 = Asum[2] * FLT_SCALE;
@@ -367,9 +378,9 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
           jx0 = (inx - prm.jmargin) & ~3;
           jy0 = iny - prm.jmargin;
           if (region_is_fast(Bb, bp, bw, bh, jx0, jy0, L.gj))
-            regionq_load_store<CH>(sJ, Bb, bp, jx0, jy0, L.gj, glv);
+            regionq_load_store<CH, G>(sJ, Bb, bp, jx0, jy0, L.gj, glv);
           else
-            regionq_stage_slow(sJ, Bb, bp, bw, bh, jx0, jy0, L.gj, glv);
+            regionq_stage_slow<G>(sJ, Bb, bp, bw, bh, jx0, jy0, L.gj, glv);
           staged = true;
         }
         __syncthreads();
@@ -401,7 +412,7 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
         float bsum[2];
         {
           const int part[2] = {b1, b2};
-          row_sums_exact_f32<2>(part, bsum);
+          group_sums_exact_f32<2, G>(part, bsum);
         }
         const float fb1 = bsum[0] * FLT_SCALE, fb2 = bsum[1] * FLT_SCALE;
         const float dx = (A12 * fb2 - A22 * fb1) * D;
@@ -412,7 +423,7 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
         ny = cy + half;
         if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) {
           active = false;
-        } else if (j > 0 && fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01) {
+        } else if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {  // == "< 0.01" in double
           nx -= dx * 0.5f;
           ny -= dy * 0.5f;
           active = false;
@@ -436,8 +447,8 @@ __device__ void lkq_track(const PyrView& A, const PyrView& B, int stream, bool a
 }
 
 // flags bit0 = forward found, bit1 = backward found, bit2 = verified (kept); see lk_fb_kernel.
-template <int NS>
-__global__ __launch_bounds__(64, 2) void lkq_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
+template <int NS, int G>
+__global__ __launch_bounds__(64, 3) void lkq_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
                                                     const int* __restrict__ n, int cap, int quads, int nstreams,
                                                     LkParams prm, float2* __restrict__ fwd,
                                                     uint8_t* __restrict__ flags) {
@@ -448,18 +459,19 @@ __global__ __launch_bounds__(64, 2) void lkq_fb_kernel(PyrView P, PyrView C, con
   const int stream = grp * 8 + xcd, quad = local - grp * quads;
   if (stream >= nstreams) return;
   const int n0 = n[stream];
-  if (4 * quad >= n0) return;
+  constexpr int F = 64 / G;
+  if (F * quad >= n0) return;
   const int lane = threadIdx.x & 63;
-  const int f = 4 * quad + (lane >> 4);
+  const int f = F * quad + lane / G;
   const bool alive = f < n0;
-  const LkQuadSmem L = lkq_smem_layout(prm.win, prm.jmargin);
+  const LkQuadSmem L = lkq_smem_layout(prm.win, prm.jmargin, F);
   double2 p0 = make_double2(0.0, 0.0);
   if (alive) p0 = xy[(long long)stream * cap + f];
   const float p0x = (float)p0.x, p0y = (float)p0.y;
   float qx, qy, rx, ry;
   bool st1, st2;
-  lkq_track<NS>(P, C, stream, alive, p0x, p0y, qx, qy, st1, prm, smem, L);
-  lkq_track<NS>(C, P, stream, alive && st1, qx, qy, rx, ry, st2, prm, smem, L);
+  lkq_track<NS, G>(P, C, stream, alive, p0x, p0y, qx, qy, st1, prm, smem, L);
+  lkq_track<NS, G>(C, P, stream, alive && st1, qx, qy, rx, ry, st2, prm, smem, L);
   uint8_t flag = 0;
   if (alive && st1) {
     flag |= 1;
@@ -469,27 +481,28 @@ __global__ __launch_bounds__(64, 2) void lkq_fb_kernel(PyrView P, PyrView C, con
       if (sqrt(ddx * ddx + ddy * ddy) <= prm.backtrack_thr) flag |= 4;
     }
   }
-  if (alive && (lane & 15) == 0) {
+  if (alive && (lane % G) == 0) {
     fwd[(long long)stream * cap + f] = make_float2(qx, qy);
     flags[(long long)stream * cap + f] = flag;
   }
 }
 
-template <int NS>
-__global__ __launch_bounds__(64, 2) void lkq_points_kernel(PyrView P, PyrView C, const float2* __restrict__ pts, int n,
+template <int NS, int G>
+__global__ __launch_bounds__(64, 3) void lkq_points_kernel(PyrView P, PyrView C, const float2* __restrict__ pts, int n,
                                                         LkParams prm, float2* __restrict__ out,
                                                         uint8_t* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int lane = threadIdx.x & 63;
-  const int f = 4 * blockIdx.x + (lane >> 4);
+  constexpr int F = 64 / G;
+  const int f = F * blockIdx.x + lane / G;
   const bool alive = f < n;
-  const LkQuadSmem L = lkq_smem_layout(prm.win, prm.jmargin);
+  const LkQuadSmem L = lkq_smem_layout(prm.win, prm.jmargin, F);
   float2 p = make_float2(0.f, 0.f);
   if (alive) p = pts[f];
   float qx, qy;
   bool st;
-  lkq_track<NS>(P, C, 0, alive, p.x, p.y, qx, qy, st, prm, smem, L);
-  if (alive && (lane & 15) == 0) {
+  lkq_track<NS, G>(P, C, 0, alive, p.x, p.y, qx, qy, st, prm, smem, L);
+  if (alive && (lane % G) == 0) {
     out[f] = make_float2(qx, qy);
     status[f] = st ? 1 : 0;
   }
