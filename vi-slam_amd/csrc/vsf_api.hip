@@ -205,12 +205,15 @@ int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hi
     return VSF_OK;
   }
   dim3 grid((unsigned)(8 * c->cap * ((streams + 7) / 8)));  // 8 XCD residue classes x streams x features
-  if (c->lk.seglen <= 8)
-    hipLaunchKernelGGL(lk_fb_kernel<8>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, streams,
-                       c->lk, c->d_fwd, c->d_flags);
-  else
-    hipLaunchKernelGGL(lk_fb_kernel<16>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, streams,
-                       c->lk, c->d_fwd, c->d_flags);
+#define VSF_LAUNCH_W(SEG)                                                                                         \
+  hipLaunchKernelGGL(lk_fb_kernel<SEG>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, streams, \
+                     c->lk, c->d_fwd, c->d_flags)
+  switch (lk_seg_template(c->lk.seglen)) {
+    case 7: VSF_LAUNCH_W(7); break;
+    case 8: VSF_LAUNCH_W(8); break;
+    default: VSF_LAUNCH_W(16); break;
+  }
+#undef VSF_LAUNCH_W
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
 }
@@ -484,6 +487,13 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     double e = p->klt_eps;
     e = e < 0. ? 0. : (e > 10. ? 10. : e);
     k.eps2 = e * e;
+    if (k.eps2 >= 1e-30) {
+      k.eps2_lo = nextafterf((float)(k.eps2 * (1.0 - 1e-6)), 0.f);
+      k.eps2_hi = nextafterf((float)(k.eps2 * (1.0 + 1e-6)), INFINITY);
+    } else {  // degenerate eps: always decide in double
+      k.eps2_lo = -1.f;
+      k.eps2_hi = INFINITY;
+    }
     k.min_eig_thr = p->min_eig_thr;
     k.backtrack_thr = p->backtrack_thr;
     k.jmargin = 3;
@@ -852,12 +862,17 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
         default: VSF_LAUNCH_QP(4); break;
       }
 #undef VSF_LAUNCH_QP
-    } else if (c->lk.seglen <= 8)
-      hipLaunchKernelGGL(lk_points_kernel<8>, dim3(n), dim3(64), c->lks.total, nullptr, P, C, d_in, n, c->lk, d_out,
-                         d_st);
-    else
-      hipLaunchKernelGGL(lk_points_kernel<16>, dim3(n), dim3(64), c->lks.total, nullptr, P, C, d_in, n, c->lk,
-                         d_out, d_st);
+    } else {
+#define VSF_LAUNCH_WP(SEG)                                                                                      \
+  hipLaunchKernelGGL(lk_points_kernel<SEG>, dim3(n), dim3(64), c->lks.total, nullptr, P, C, d_in, n, c->lk, d_out, \
+                     d_st)
+      switch (lk_seg_template(c->lk.seglen)) {
+        case 7: VSF_LAUNCH_WP(7); break;
+        case 8: VSF_LAUNCH_WP(8); break;
+        default: VSF_LAUNCH_WP(16); break;
+      }
+#undef VSF_LAUNCH_WP
+    }
     if (hipGetLastError() != hipSuccess) rc = VSF_E_HIP;
   }
   if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = VSF_E_HIP;

@@ -15,6 +15,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef VSF_SUM_LDS
+#define VSF_SUM_LDS 1  // exact sums through the LDS atomic unit (0: DPP + v_readlane only)
+#endif
+
 namespace vsf {
 
 constexpr int MAXL = 8;      // pyramid levels supported (klt_max_level <= 7)
@@ -34,6 +38,8 @@ struct LkParams {
   int seglen;     // pixels per lane
   int max_count;  // clamped iteration count
   double eps2;    // clamped eps, squared
+  float eps2_lo;  // float s = dx^2 + dy^2 <= eps2_lo  =>  the double test is true
+  float eps2_hi;  // s >= eps2_hi  =>  the double test is false; in between the double test runs
   double min_eig_thr;
   double backtrack_thr;
   int jmargin;    // extra margin staged around the J window
@@ -161,6 +167,75 @@ __device__ __forceinline__ void wave_sums_exact_f32(const int (&p)[N], float (&o
   }
 }
 
+// The same sums through the LDS ATOMIC unit.  The kernel is VALU-issue bound while the LDS pipe idles, so
+// only the first NRAW butterfly steps run as DPP adds (the values still fit int32: NRAW = 3 needs
+// |p| < 2^28, NRAW = 2 needs |p| < 2^29); then one lane of every 2^NRAW adds its partial sum as a
+// 64-bit integer into an LDS accumulator (lane 0 stores, the others ds_add_u64: LDS operations of one
+// wave execute in issue order), and every lane reads the exact total back.  The total is converted
+// to float32 with ONE rounding: v_cvt_f32_i32 when it fits 32 bits, through double otherwise.
+template <int N, int NRAW>
+__device__ __forceinline__ void wave_sums_exact_lds(const int (&p)[N], float (&out)[N], long long* acc, int lane) {
+  int q[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = p[i] + __builtin_amdgcn_update_dpp(0, p[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] += __builtin_amdgcn_update_dpp(0, q[i], 0x4E, 0xf, 0xf, false);
+  if constexpr (NRAW == 3) {
+#pragma unroll
+    for (int i = 0; i < N; i++) q[i] += __builtin_amdgcn_update_dpp(0, q[i], 0x141, 0xf, 0xf, false);
+  }
+  constexpr int LM = (1 << NRAW) - 1;
+  // LDS byte address of the accumulators.  The three steps are written as inline asm: left to the
+  // compiler, the atomic is "optimised" into a serial v_readlane loop over the active lanes, which
+  // is exactly the VALU work this routine exists to avoid.
+  const unsigned int a32 =
+      (unsigned int)(size_t)(__attribute__((address_space(3))) void*)acc;
+  long long q64[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q64[i] = (long long)q[i];
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const unsigned int ai = a32 + 8u * (unsigned int)i;
+      asm volatile("ds_write_b64 %0, %1" ::"v"(ai), "v"(q64[i]) : "memory");
+    }
+  }
+  // convergent barriers keep the store, the adds and the loads in this order in the instruction
+  // stream (per lane they are mutually exclusive, so nothing else orders them for the compiler)
+  __builtin_amdgcn_wave_barrier();
+  if (lane != 0 && (lane & LM) == 0) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      const unsigned int ai = a32 + 8u * (unsigned int)i;
+      asm volatile("ds_add_u64 %0, %1" ::"v"(ai), "v"(q64[i]) : "memory");
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  long long t[N];
+  if constexpr (N == 2) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1])
+                 : "v"(a32)
+                 : "memory");
+  } else {
+    static_assert(N == 3, "two or three sums");
+    asm volatile(
+        "ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2])
+        : "v"(a32)
+        : "memory");
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)t[i]);
+    const int hi = __builtin_amdgcn_readfirstlane((int)(t[i] >> 32));
+    if (hi == (lo >> 31))
+      out[i] = (float)lo;
+    else
+      out[i] = (float)((double)hi * 4294967296.0 + (double)(unsigned int)lo);
+  }
+}
+
 __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
   w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
   w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
@@ -176,6 +251,11 @@ typedef short vsf_i16x2 __attribute__((ext_vector_type(2)));
 // fourth bilinear weight, 2^14 - w00 - w01 - w10, can come out as -1 after rounding.
 __device__ __forceinline__ int sdot2(unsigned int a, unsigned int b, int c) {
   return __builtin_amdgcn_sdot2(__builtin_bit_cast(vsf_i16x2, a), __builtin_bit_cast(vsf_i16x2, b), c, false);
+}
+
+// (lo & 0xffff) | (hi << 16) in one v_perm_b32
+__device__ __forceinline__ unsigned int pack_lo16(int lo, int hi) {
+  return __builtin_amdgcn_perm((unsigned int)hi, (unsigned int)lo, 0x05040100u);
 }
 
 // Reads NA+... dwords of an LDS byte row starting at byte offset `boff` and returns, in A[], the byte
@@ -252,8 +332,19 @@ struct LkSmem {
   RegionGeom gi;  // template patch of I: (win+3) rows, covers win+3 columns at any 4-byte phase
   RegionGeom gj;  // J region: window + margin
   int d_pitch;    // gradient patch (win+1)^2, packed (Ix | Iy<<16) int32 (generic path only)
-  int off_j, off_d, total;
+  int off_j, off_d;
+  int off_acc;   // 4 x int64 accumulators of the exact sums
+  int off_mask;  // per lane: NP dwords, 16-bit masks of the window pixels the lane owns (pair-packed)
+  int total;
 };
+
+// Pixels per lane: the window row is cut into nseg = 64 / win segments of seglen pixels.
+__host__ __device__ inline int lk_seglen(int win) {
+  const int nseg = 64 / win;
+  return (win + nseg - 1) / nseg;
+}
+// Kernel instantiation (compile-time pixels per lane) that serves a given seglen.
+__host__ __device__ inline int lk_seg_template(int seglen) { return seglen <= 7 ? 7 : (seglen <= 8 ? 8 : 16); }
 
 __host__ __device__ inline RegionGeom vsf_region_geom(int cols_needed, int rows) {
   RegionGeom g;
@@ -272,7 +363,10 @@ __host__ __device__ inline LkSmem lk_smem_layout(int win, int jmargin) {
   const int si = s.gi.pitch * s.gi.rows + 32;  // +slack: dword-granular readers may run past a row end
   s.off_j = (si + 15) & ~15;
   s.off_d = s.off_j + ((s.gj.pitch * s.gj.rows + 32 + 15) & ~15);
-  s.total = s.off_d + ((s.d_pitch * (win + 1) * 4 + 15) & ~15);
+  s.off_acc = s.off_d + ((s.d_pitch * (win + 1) * 4 + 15) & ~15);
+  s.off_mask = s.off_acc + 32;
+  const int np = (lk_seg_template(lk_seglen(win)) + 1) / 2;
+  s.total = s.off_mask + 64 * 4 * np;
   return s;
 }
 
@@ -334,6 +428,8 @@ __device__ __forceinline__ void region_stage_slow(uint8_t* dst, const uint8_t* _
 
 // Tracks one point from pyramid A (template, derivatives) to pyramid B.  Wave-uniform control flow.
 // Returns the OpenCV status (true = found); out = nextPts.
+// SEG = compile-time pixels per lane (>= prm.seglen).  Gradients are held pair-packed
+// (IxP[k2] = Ix[2k2] | Ix[2k2+1] << 16, same for Iy), so that every sum of products is a v_dot2.
 template <int SEG>
 __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, float ptx, float pty,
                                float& outx, float& outy, const LkParams& prm, uint8_t* smem,
@@ -341,16 +437,20 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
   constexpr int NA = (SEG + 1 + 3) / 4;     // aligned dwords holding SEG+1 bytes
   constexpr int NI = (SEG <= 8) ? 3 : 6;    // I-patch dwords per lane (win <= 21 / <= 31)
   constexpr int NJ = (SEG <= 8) ? 4 : 7;    // J-region dwords per lane (jmargin 3)
+  constexpr int NP = (SEG + 1) / 2;         // pixel pairs per lane
+  constexpr int NRAW = (SEG <= 8) ? 3 : 2;  // raw DPP steps of the exact sums (see wave_sums_exact_lds)
   const int lane = threadIdx.x & 63;
   const int win = prm.win;
   const int r = lane / prm.nseg;
   const int x0 = (lane - r * prm.nseg) * prm.seglen;
   const bool owner = (r < win) && (x0 < win);                // lane owns at least one window pixel
-  const int cnt = owner ? min(prm.seglen, win - x0) : 0;
   const int rr = owner ? r : 0, xx0 = owner ? x0 : 0;        // idle lanes read a valid (unused) place
   uint8_t* sI = smem;
   uint8_t* sJ = smem + L.off_j;
   int* sD = reinterpret_cast<int*>(smem + L.off_d);
+  long long* sAcc = reinterpret_cast<long long*>(smem + L.off_acc);
+  const unsigned int* sMask = reinterpret_cast<const unsigned int*>(smem + L.off_mask) + lane * NP;
+  const int rowI = __mul24(rr, L.gi.pitch), rowJ = __mul24(rr, L.gj.pitch);
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
   const int maxLevel = A.nlevels - 1;
@@ -371,7 +471,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     }
     px -= half;
     py -= half;
-    const int ipx = (int)floorf(px), ipy = (int)floorf(py);
+    const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px));
+    const int ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
     const int aw = A.w[level], ah = A.h[level];
     const bool in_range = !(ipx < -win || ipx >= aw || ipy < -win || ipy >= ah);
     const int xaI = (ipx - 1) & ~3;
@@ -395,16 +496,24 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     bool level_ok = in_range;
     if (!in_range && level == 0) status = false;
 
-    int IxIy[SEG];  // template gradients, (Ix & 0xffff) | (Iy << 16)
+    unsigned int IxP[NP], IyP[NP];  // template gradients, pair-packed, zero where the lane owns no pixel
     int cI1 = 0, cI2 = 0;
     float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
     if (level_ok) {
-      int Iw[SEG];
+      int Iw[SEG + 1];
+      Iw[SEG] = 0;
+      const float fa = px - (float)ipx, fb = py - (float)ipy;
       int iw00, iw01, iw10, iw11;
-      bilinear_weights(px - (float)ipx, py - (float)ipy, iw00, iw01, iw10, iw11);
+      bilinear_weights(fa, fb, iw00, iw01, iw10, iw11);
+      iw00 = __builtin_amdgcn_readfirstlane(iw00);
+      iw01 = __builtin_amdgcn_readfirstlane(iw01);
+      iw10 = __builtin_amdgcn_readfirstlane(iw10);
+      iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
       const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
       const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
-      int a11 = 0, a12 = 0, a22 = 0;
+      unsigned int pm[NP];
+#pragma unroll
+      for (int k2 = 0; k2 < NP; k2++) pm[k2] = sMask[k2];
       // every tap of every window pixel lies inside the level image: no zero-padded gradient involved
       const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < aw && ipy + win < ah;
       if (interior) {
@@ -415,10 +524,11 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         constexpr int NC = SEG + 2;            // V columns: window columns xx0-1 .. xx0+SEG
         constexpr int NAV = (NC + 1 + 3) / 4;  // aligned dwords holding NC+1 bytes
         unsigned int R0[NAV], R1[NAV], R2[NAV], R3[NAV];
-        lds_stream<NAV>(sI + (rr + 0) * L.gi.pitch, oI + xx0, R0);
-        lds_stream<NAV>(sI + (rr + 1) * L.gi.pitch, oI + xx0, R1);
-        lds_stream<NAV>(sI + (rr + 2) * L.gi.pitch, oI + xx0, R2);
-        lds_stream<NAV>(sI + (rr + 3) * L.gi.pitch, oI + xx0, R3);
+        const uint8_t* rI = sI + rowI;
+        lds_stream<NAV>(rI, oI + xx0, R0);
+        lds_stream<NAV>(rI + L.gi.pitch, oI + xx0, R1);
+        lds_stream<NAV>(rI + 2 * L.gi.pitch, oI + xx0, R2);
+        lds_stream<NAV>(rI + 3 * L.gi.pitch, oI + xx0, R3);
         int V0[NC], V1[NC], V2[NC];
         const bool wpos = iw11 >= 0;  // the other three weights are rounded products of non-negatives
         bilinear_row<NC, NAV, 0>(wpos, R0, R1, W0, W1, V0);
@@ -430,14 +540,20 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           T0[c] = __mul24(V0[c] + V2[c], 3) + __mul24(V1[c], 10);  // < 2^27
           T1[c] = V2[c] - V0[c];
         }
+        int ixv[SEG + 1], iyv[SEG + 1];
+        ixv[SEG] = 0;
+        iyv[SEG] = 0;
 #pragma unroll
         for (int k = 0; k < SEG; k++) {
-          const bool own = k < cnt;
-          const int ixval = VSF_DESCALE(T0[k + 2] - T0[k], W_BITS);
-          const int iyval = VSF_DESCALE(3 * (T1[k] + T1[k + 2]) + 10 * T1[k + 1], W_BITS);
+          ixv[k] = VSF_DESCALE(T0[k + 2] - T0[k], W_BITS);
+          iyv[k] = VSF_DESCALE(3 * (T1[k] + T1[k + 2]) + 10 * T1[k + 1], W_BITS);
           Iw[k] = VSF_DESCALE(V1[k + 1], W_BITS - 5);
-          // pixels a lane does not own carry zero gradients, so they add nothing to any sum
-          IxIy[k] = own ? ((ixval & 0xffff) | (iyval << 16)) : 0;
+        }
+        // pixels a lane does not own carry zero gradients, so they add nothing to any sum
+#pragma unroll
+        for (int k2 = 0; k2 < NP; k2++) {
+          IxP[k2] = pack_lo16(ixv[2 * k2], ixv[2 * k2 + 1]) & pm[k2];
+          IyP[k2] = pack_lo16(iyv[2 * k2], iyv[2 * k2 + 1]) & pm[k2];
         }
       } else {
         // Generic path (window touches the level border): Scharr gradient patch (win+1)^2 in LDS,
@@ -467,43 +583,57 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         }
         __syncthreads();
         unsigned int R0[NA], R1[NA];
-        lds_stream<NA>(sI + (rr + 1) * L.gi.pitch, oI + 1 + xx0, R0);
-        lds_stream<NA>(sI + (rr + 2) * L.gi.pitch, oI + 1 + xx0, R1);
-        BilinearRow<0, SEG, NA, (1 << (W_BITS - 5 - 1))>::run(R0, R1, W0, W1, Iw);
+        lds_stream<NA>(sI + rowI + L.gi.pitch, oI + 1 + xx0, R0);
+        lds_stream<NA>(sI + rowI + 2 * L.gi.pitch, oI + 1 + xx0, R1);
+        int Iv[SEG];
+        BilinearRow<0, SEG, NA, (1 << (W_BITS - 5 - 1))>::run(R0, R1, W0, W1, Iv);
         const int* d0 = sD + rr * L.d_pitch + xx0;
         const int* d1 = d0 + L.d_pitch;
+        int ixv[SEG + 1], iyv[SEG + 1];
+        ixv[SEG] = 0;
+        iyv[SEG] = 0;
 #pragma unroll
         for (int k = 0; k < SEG; k++) {
-          Iw[k] = Iw[k] >> (W_BITS - 5);
-          int ixval = 0, iyval = 0;
-          if (k < cnt) {
+          Iw[k] = Iv[k] >> (W_BITS - 5);
+          ixv[k] = 0;
+          iyv[k] = 0;
+          if (k < prm.seglen) {  // d0[k + 1] stays inside the (win+1)-wide patch for every pixel read
             const int p00 = d0[k], p01 = d0[k + 1], p10 = d1[k], p11 = d1[k + 1];
-            ixval = VSF_DESCALE(__mul24((int)(short)(p00 & 0xffff), iw00) + __mul24((int)(short)(p01 & 0xffff), iw01) +
-                                    __mul24((int)(short)(p10 & 0xffff), iw10) +
-                                    __mul24((int)(short)(p11 & 0xffff), iw11),
-                                W_BITS);
-            iyval = VSF_DESCALE(__mul24(p00 >> 16, iw00) + __mul24(p01 >> 16, iw01) + __mul24(p10 >> 16, iw10) +
-                                    __mul24(p11 >> 16, iw11),
-                                W_BITS);
+            ixv[k] = VSF_DESCALE(__mul24((int)(short)(p00 & 0xffff), iw00) + __mul24((int)(short)(p01 & 0xffff), iw01) +
+                                     __mul24((int)(short)(p10 & 0xffff), iw10) +
+                                     __mul24((int)(short)(p11 & 0xffff), iw11),
+                                 W_BITS);
+            iyv[k] = VSF_DESCALE(__mul24(p00 >> 16, iw00) + __mul24(p01 >> 16, iw01) + __mul24(p10 >> 16, iw10) +
+                                     __mul24(p11 >> 16, iw11),
+                                 W_BITS);
           }
-          IxIy[k] = (ixval & 0xffff) | (iyval << 16);
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < NP; k2++) {
+          IxP[k2] = pack_lo16(ixv[2 * k2], ixv[2 * k2 + 1]) & pm[k2];
+          IyP[k2] = pack_lo16(iyv[2 * k2], iyv[2 * k2 + 1]) & pm[k2];
         }
       }
       // b = sum (Jw - Iw) * (Ix, Iy) = sum Jw * (Ix, Iy) - (cI1, cI2): the template's own part is a
       // per-lane constant of the level, so the iterations neither subtract per pixel nor keep Iw live
+      int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
-      for (int k = 0; k < SEG; k++) {
-        const int ix = (int)(short)(IxIy[k] & 0xffff), iy = IxIy[k] >> 16;
-        a11 += __mul24(ix, ix);
-        a12 += __mul24(ix, iy);
-        a22 += __mul24(iy, iy);
-        cI1 += __mul24(Iw[k], ix);
-        cI2 += __mul24(Iw[k], iy);
+      for (int k2 = 0; k2 < NP; k2++) {
+        const unsigned int iwp = pack_lo16(Iw[2 * k2], Iw[2 * k2 + 1]);  // 0 <= Iw <= 8160
+        a11 = sdot2(IxP[k2], IxP[k2], a11);
+        a12 = sdot2(IxP[k2], IyP[k2], a12);
+        a22 = sdot2(IyP[k2], IyP[k2], a22);
+        cI1 = sdot2(iwp, IxP[k2], cI1);
+        cI2 = sdot2(iwp, IyP[k2], cI2);
       }
       float Asum[3];
       {
         const int part[3] = {a11, a12, a22};
+#if VSF_SUM_LDS
+        wave_sums_exact_lds<3, NRAW>(part, Asum, sAcc, lane);
+#else
         wave_sums_exact_f32<3>(part, Asum);
+#endif
       }
       A11 = Asum[0] * FLT_SCALE;
       A12 = Asum[1] * FLT_SCALE;
@@ -523,7 +653,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       float cx = nx - half, cy = ny - half;  // nextPt - halfWin
       float pdx = 0.f, pdy = 0.f;
       for (int j = 0; j < prm.max_count; j++) {
-        const int inx = (int)floorf(cx), iny = (int)floorf(cy);
+        const int inx = __builtin_amdgcn_readfirstlane((int)floorf(cx));
+        const int iny = __builtin_amdgcn_readfirstlane((int)floorf(cy));
         if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
           if (level == 0) status = false;
           break;
@@ -545,27 +676,41 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         }
         int iw00, iw01, iw10, iw11;
         bilinear_weights(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
+        iw00 = __builtin_amdgcn_readfirstlane(iw00);
+        iw01 = __builtin_amdgcn_readfirstlane(iw01);
+        iw10 = __builtin_amdgcn_readfirstlane(iw10);
+        iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int b1 = -cI1, b2 = -cI2;
         {
           unsigned int R0[NA], R1[NA];
-          const uint8_t* row0 = sJ + (rr + iny - jy0) * L.gj.pitch;
-          lds_stream<NA>(row0, xx0 + inx - jx0, R0);
-          lds_stream<NA>(row0 + L.gj.pitch, xx0 + inx - jx0, R1);
+          const uint8_t* row0 = sJ + rowJ + (iny - jy0) * L.gj.pitch;
+          lds_stream<NA>(row0, xx0 + (inx - jx0), R0);
+          lds_stream<NA>(row0 + L.gj.pitch, xx0 + (inx - jx0), R1);
           const unsigned int V0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
           const unsigned int V1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
-          int Jw[SEG];
-          bilinear_row<SEG, NA, (1 << (W_BITS - 5 - 1))>(iw11 >= 0, R0, R1, V0, V1, Jw);
+          int Jw[SEG + 1];
+          Jw[SEG] = 0;
+          {
+            int Jr[SEG];
+            bilinear_row<SEG, NA, (1 << (W_BITS - 5 - 1))>(iw11 >= 0, R0, R1, V0, V1, Jr);
 #pragma unroll
-          for (int k = 0; k < SEG; k++) {
-            const int jv = Jw[k] >> (W_BITS - 5);
-            b1 += __mul24(jv, (int)(short)(IxIy[k] & 0xffff));
-            b2 += __mul24(jv, IxIy[k] >> 16);
+            for (int k = 0; k < SEG; k++) Jw[k] = Jr[k] >> (W_BITS - 5);  // 0 <= Jw <= 8160
+          }
+#pragma unroll
+          for (int k2 = 0; k2 < NP; k2++) {
+            const unsigned int jp = pack_lo16(Jw[2 * k2], Jw[2 * k2 + 1]);
+            b1 = sdot2(jp, IxP[k2], b1);
+            b2 = sdot2(jp, IyP[k2], b2);
           }
         }
         float bsum[2];
         {
           const int part[2] = {b1, b2};
+#if VSF_SUM_LDS
+          wave_sums_exact_lds<2, NRAW>(part, bsum, sAcc, lane);
+#else
           wave_sums_exact_f32<2>(part, bsum);
+#endif
         }
         const float fb1 = bsum[0] * FLT_SCALE, fb2 = bsum[1] * FLT_SCALE;
         const float dx = (A12 * fb2 - A22 * fb1) * D;
@@ -574,7 +719,19 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         cy += dy;
         nx = cx + half;
         ny = cy + half;
-        if ((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) break;
+        // cv: dx*dx + dy*dy <= eps^2 evaluated in double.  The float value s is within 3 ulp of the
+        // exact sum, so outside a 1e-6 relative band around eps^2 the float compare already decides.
+        {
+          const float s = __fmaf_rn(dx, dx, dy * dy);
+          bool conv;
+          if (s <= prm.eps2_lo)
+            conv = true;
+          else if (s >= prm.eps2_hi)
+            conv = false;
+          else
+            conv = (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2;
+          if (conv) break;
+        }
         // cv compares the float sums with the double 0.01; (float)0.01 is the largest float below
         // 0.01, so `<= 0.01f` in float is the same predicate
         if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
@@ -599,11 +756,27 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
   return status;
 }
 
+// Fills the per-lane ownership masks in LDS (once per kernel): 16 bits per window pixel the lane owns.
+template <int SEG>
+__device__ __forceinline__ void lk_init_masks(const LkParams& prm, uint8_t* smem, const LkSmem& L) {
+  constexpr int NP = (SEG + 1) / 2;
+  const int lane = threadIdx.x & 63;
+  const int r = lane / prm.nseg;
+  const int x0 = (lane - r * prm.nseg) * prm.seglen;
+  const bool owner = (r < prm.win) && (x0 < prm.win);
+  const int cnt = owner ? min(prm.seglen, prm.win - x0) : 0;
+  unsigned int* m = reinterpret_cast<unsigned int*>(smem + L.off_mask) + lane * NP;
+#pragma unroll
+  for (int k2 = 0; k2 < NP; k2++)
+    m[k2] = (2 * k2 + 1 < cnt) ? 0xffffffffu : ((2 * k2 < cnt) ? 0x0000ffffu : 0u);
+  __syncthreads();
+}
+
 // flags bit0 = forward found, bit1 = backward found, bit2 = verified (kept).
 // ref: FeatureTrackerLucasKanade.cpp:36-80 (forward, backward on the forward survivors, then
 // ||back - original||_2 <= threshold in double against the ORIGINAL double position).
 template <int SEG>
-__global__ __launch_bounds__(64) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
+__global__ __launch_bounds__(64, (SEG <= 8 ? 4 : 2)) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
                                                    const int* __restrict__ n, int cap, int nstreams,
                                                    LkParams prm, float2* __restrict__ fwd,
                                                    uint8_t* __restrict__ flags) {
@@ -616,6 +789,7 @@ __global__ __launch_bounds__(64) void lk_fb_kernel(PyrView P, PyrView C, const d
   const int stream = grp * 8 + xcd, f = local - grp * cap;
   if (stream >= nstreams || f >= n[stream]) return;
   const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
+  lk_init_masks<SEG>(prm, smem, L);
   const double2 p0 = xy[(long long)stream * cap + f];
   const float p0x = (float)p0.x, p0y = (float)p0.y;  // :210 double -> float narrowing
   float qx, qy;
@@ -637,13 +811,14 @@ __global__ __launch_bounds__(64) void lk_fb_kernel(PyrView P, PyrView C, const d
 
 // plain cv::calcOpticalFlowPyrLK on a point list (parity tests): one wave per point
 template <int SEG>
-__global__ __launch_bounds__(64) void lk_points_kernel(PyrView P, PyrView C, const float2* __restrict__ pts,
+__global__ __launch_bounds__(64, (SEG <= 8 ? 4 : 2)) void lk_points_kernel(PyrView P, PyrView C, const float2* __restrict__ pts,
                                                        int n, LkParams prm, float2* __restrict__ out,
                                                        uint8_t* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
   const int f = blockIdx.x;
   if (f >= n) return;
   const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
+  lk_init_masks<SEG>(prm, smem, L);
   const float2 p = pts[f];
   float qx, qy;
   const bool st = lk_track_point<SEG>(P, C, 0, p.x, p.y, qx, qy, prm, smem, L);
