@@ -495,6 +495,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
       k.eps2_hi = INFINITY;
     }
     k.min_eig_thr = p->min_eig_thr;
+    k.min_eig_c1 = nextafterf((float)((p->min_eig_thr > 0. ? p->min_eig_thr : 0.) * 2.0 * k.win * k.win * 1.001), INFINITY);
     k.backtrack_thr = p->backtrack_thr;
     k.jmargin = 3;
     k.q_nseg = (k.win + 7) / 8;

@@ -41,6 +41,7 @@ struct LkParams {
   float eps2_lo;  // float s = dx^2 + dy^2 <= eps2_lo  =>  the double test is true
   float eps2_hi;  // s >= eps2_hi  =>  the double test is false; in between the double test runs
   double min_eig_thr;
+  float min_eig_c1;  // max(threshold, 0) * 2 win^2 * 1.001: see the shortcut in lk_track_point
   double backtrack_thr;
   int jmargin;    // extra margin staged around the J window
   int q_nseg;     // four-features-per-wave variant: segments per window row (<= 8 pixels each)
@@ -167,6 +168,23 @@ __device__ __forceinline__ void wave_sums_exact_f32(const int (&p)[N], float (&o
   }
 }
 
+// v_readfirstlane the compiler cannot look through: the result is an SGPR, and everything computed
+// from it stays on the scalar unit instead of being folded back into vector instructions.
+// gfx940/950 need one wait state between a VALU write of a VGPR and a v_readlane of it, and two
+// between a VALU write of an SGPR and a VALU read of it; the compiler inserts them for its own
+// instructions but cannot see inside an asm statement, so they are part of it (measured: without
+// the leading s_nop the lane read returns the register's previous value).
+__device__ __forceinline__ int to_sgpr(int v) {
+  int s;
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(s) : "v"(v));
+  return s;
+}
+__device__ __forceinline__ int to_sgpr(float v) {
+  int s;
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(s) : "v"(v));
+  return s;
+}
+
 // The same sums through the LDS ATOMIC unit.  The kernel is VALU-issue bound while the LDS pipe idles, so
 // only the first NRAW butterfly steps run as DPP adds (the values still fit int32: NRAW = 3 needs
 // |p| < 2^28, NRAW = 2 needs |p| < 2^29); then one lane of every 2^NRAW adds its partial sum as a
@@ -190,25 +208,29 @@ __device__ __forceinline__ void wave_sums_exact_lds(const int (&p)[N], float (&o
   // is exactly the VALU work this routine exists to avoid.
   const unsigned int a32 =
       (unsigned int)(size_t)(__attribute__((address_space(3))) void*)acc;
+  static_assert(N == 2 || N == 3, "two or three sums");
   long long q64[N];
 #pragma unroll
   for (int i = 0; i < N; i++) q64[i] = (long long)q[i];
   if (lane == 0) {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      const unsigned int ai = a32 + 8u * (unsigned int)i;
-      asm volatile("ds_write_b64 %0, %1" ::"v"(ai), "v"(q64[i]) : "memory");
-    }
+    if constexpr (N == 2)
+      asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" ::"v"(a32), "v"(q64[0]), "v"(q64[1])
+                   : "memory");
+    else
+      asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8\n\tds_write_b64 %0, %3 offset:16" ::"v"(a32),
+                   "v"(q64[0]), "v"(q64[1]), "v"(q64[N - 1])
+                   : "memory");
   }
   // convergent barriers keep the store, the adds and the loads in this order in the instruction
   // stream (per lane they are mutually exclusive, so nothing else orders them for the compiler)
   __builtin_amdgcn_wave_barrier();
   if (lane != 0 && (lane & LM) == 0) {
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-      const unsigned int ai = a32 + 8u * (unsigned int)i;
-      asm volatile("ds_add_u64 %0, %1" ::"v"(ai), "v"(q64[i]) : "memory");
-    }
+    if constexpr (N == 2)
+      asm volatile("ds_add_u64 %0, %1\n\tds_add_u64 %0, %2 offset:8" ::"v"(a32), "v"(q64[0]), "v"(q64[1]) : "memory");
+    else
+      asm volatile("ds_add_u64 %0, %1\n\tds_add_u64 %0, %2 offset:8\n\tds_add_u64 %0, %3 offset:16" ::"v"(a32),
+                   "v"(q64[0]), "v"(q64[1]), "v"(q64[N - 1])
+                   : "memory");
   }
   __builtin_amdgcn_wave_barrier();
   long long t[N];
@@ -218,22 +240,36 @@ __device__ __forceinline__ void wave_sums_exact_lds(const int (&p)[N], float (&o
                  : "v"(a32)
                  : "memory");
   } else {
-    static_assert(N == 3, "two or three sums");
     asm volatile(
         "ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
-        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2])
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[N - 1])
         : "v"(a32)
         : "memory");
   }
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    const int lo = __builtin_amdgcn_readfirstlane((int)(unsigned int)(unsigned long long)t[i]);
-    const int hi = __builtin_amdgcn_readfirstlane((int)(t[i] >> 32));
+    // scalar from here on: the range test and the recombination cost no vector instruction
+    const int lo = to_sgpr((int)(unsigned int)(unsigned long long)t[i]);
+    const int hi = to_sgpr((int)(t[i] >> 32));
     if (hi == (lo >> 31))
       out[i] = (float)lo;
     else
       out[i] = (float)((double)hi * 4294967296.0 + (double)(unsigned int)lo);
   }
+}
+
+// The four weights of a wave-uniform sub-pixel offset, as scalars.  cvRound(x * 2^14), x in [0, 1]:
+// scaling by 2^14 is exact, so it is applied to one factor before the product; adding 1.5 * 2^23
+// rounds the product to an integer with ties to even (the parity of the sum is the parity of the
+// integer part), which is what cvRound / rint do; the integer is then the low mantissa bits.
+__device__ __forceinline__ void bilinear_weights_uniform(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+  const float MAGIC = 12582912.f;  // 1.5 * 2^23
+  const float a1 = 1.f - a;
+  const float b1 = (1.f - b) * (float)(1 << W_BITS), b0 = b * (float)(1 << W_BITS);
+  w00 = to_sgpr(a1 * b1 + MAGIC) - 0x4B400000;
+  w01 = to_sgpr(a * b1 + MAGIC) - 0x4B400000;
+  w10 = to_sgpr(a1 * b0 + MAGIC) - 0x4B400000;
+  w11 = (1 << W_BITS) - w00 - w01 - w10;
 }
 
 __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
@@ -269,6 +305,25 @@ __device__ __forceinline__ void lds_stream(const uint8_t* row, int boff, unsigne
   for (int i = 0; i < NA + 1; i++) d[i] = w[i];
 #pragma unroll
   for (int i = 0; i < NA; i++) A[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], o);
+}
+
+// Two consecutive LDS rows (pitch a multiple of 4, rows dword aligned) read from the byte address p
+// of the first one: one address split serves both rows.
+template <int NA>
+__device__ __forceinline__ void lds_stream_at(const uint8_t* p, int pitch, unsigned int (&A0)[NA],
+                                              unsigned int (&A1)[NA]) {
+  const unsigned int o = (unsigned int)reinterpret_cast<uintptr_t>(p) & 3u;
+  const unsigned int* w0 = reinterpret_cast<const unsigned int*>(p - o);
+  const unsigned int* w1 = reinterpret_cast<const unsigned int*>(p - o + pitch);
+  unsigned int d0[NA + 1], d1[NA + 1];
+#pragma unroll
+  for (int i = 0; i < NA + 1; i++) d0[i] = w0[i];
+#pragma unroll
+  for (int i = 0; i < NA + 1; i++) d1[i] = w1[i];
+#pragma unroll
+  for (int i = 0; i < NA; i++) A0[i] = __builtin_amdgcn_alignbyte(d0[i + 1], d0[i], o);
+#pragma unroll
+  for (int i = 0; i < NA; i++) A1[i] = __builtin_amdgcn_alignbyte(d1[i + 1], d1[i], o);
 }
 
 // (byte k) | (byte k+1) << 16 of a dword stream (v_perm_b32; selector 0x0c = zero byte)
@@ -378,32 +433,38 @@ __device__ __forceinline__ bool region_is_fast(const uint8_t* src, int sp, int s
          ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
 }
 
-// Issues the aligned dword loads of a fast region into registers (no wait): task t = lane + 64*i
-// covers row t / ndw, dword t % ndw.
+// Staging map (no division): lane -> dword column xd = lane % C and row yl = lane / C, with C = 8 when
+// the region is at most 8 dwords wide and 16 otherwise; task i covers row yl + i * (64 / C).
+// Issues the aligned dword loads of a fast region into registers (no wait).  The source pointer is
+// wave-uniform, so each load is a scalar base plus a 32-bit lane offset.
 template <int N>
 __device__ __forceinline__ void region_load_regs(unsigned int (&reg)[N], const uint8_t* __restrict__ src, int sp,
                                                  int xa, int y0, const RegionGeom& g, int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
   const unsigned int* s = reinterpret_cast<const unsigned int*>(src + (long long)y0 * sp + xa);
-  const int spw = sp >> 2;
+  const unsigned int spw = (unsigned int)sp >> 2;
+  const unsigned int off = (unsigned int)yl * spw + (unsigned int)xd, step = (unsigned int)ystep * spw;
+  const bool xin = xd < g.ndw;
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    const int t = lane + 64 * i;
-    const int y = (t * g.inv) >> 16, xd = t - y * g.ndw;
     reg[i] = 0u;
-    if (y < g.rows) reg[i] = s[(long long)y * spw + xd];
+    if (xin && yl + i * ystep < g.rows) reg[i] = s[off + (unsigned int)i * step];
   }
 }
 
 template <int N>
 __device__ __forceinline__ void region_store_regs(uint8_t* dst, const unsigned int (&reg)[N], const RegionGeom& g,
                                                   int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
   unsigned int* d = reinterpret_cast<unsigned int*>(dst);
   const int pw = g.pitch >> 2;
+  const int off = yl * pw + xd, step = ystep * pw;
+  const bool xin = xd < g.ndw;
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    const int t = lane + 64 * i;
-    const int y = (t * g.inv) >> 16, xd = t - y * g.ndw;
-    if (y < g.rows) d[y * pw + xd] = reg[i];
+    if (xin && yl + i * ystep < g.rows) d[off + i * step] = reg[i];
   }
 }
 
@@ -411,12 +472,12 @@ __device__ __forceinline__ void region_store_regs(uint8_t* dst, const unsigned i
 template <int N>
 __device__ __forceinline__ void region_stage_slow(uint8_t* dst, const uint8_t* __restrict__ src, int sp, int sw,
                                                   int sh, int xa, int y0, const RegionGeom& g, int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
   unsigned int* d = reinterpret_cast<unsigned int*>(dst);
   const int pw = g.pitch >> 2;
-  for (int i = 0; i < N; i++) {
-    const int t = lane + 64 * i;
-    const int y = (t * g.inv) >> 16, xd = t - y * g.ndw;
-    if (y < g.rows) {
+  if (xd < g.ndw) {
+    for (int y = yl; y < g.rows; y += ystep) {
       const uint8_t* sr = src + (long long)reflect101(y0 + y, sh) * sp;
       unsigned int v = 0u;
 #pragma unroll
@@ -435,8 +496,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
                                float& outx, float& outy, const LkParams& prm, uint8_t* smem,
                                const LkSmem& L) {
   constexpr int NA = (SEG + 1 + 3) / 4;     // aligned dwords holding SEG+1 bytes
-  constexpr int NI = (SEG <= 8) ? 3 : 6;    // I-patch dwords per lane (win <= 21 / <= 31)
-  constexpr int NJ = (SEG <= 8) ? 4 : 7;    // J-region dwords per lane (jmargin 3)
+  constexpr int NI = (SEG <= 8) ? 3 : 9;    // I-patch staging tasks per lane (win <= 21: 24 rows / 8; <= 31: 34 / 4)
+  constexpr int NJ = (SEG <= 8) ? 4 : 10;   // J-region staging tasks per lane (jmargin 3: 28 rows / 8; 38 / 4)
   constexpr int NP = (SEG + 1) / 2;         // pixel pairs per lane
   constexpr int NRAW = (SEG <= 8) ? 3 : 2;  // raw DPP steps of the exact sums (see wave_sums_exact_lds)
   const int lane = threadIdx.x & 63;
@@ -450,7 +511,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
   int* sD = reinterpret_cast<int*>(smem + L.off_d);
   long long* sAcc = reinterpret_cast<long long*>(smem + L.off_acc);
   const unsigned int* sMask = reinterpret_cast<const unsigned int*>(smem + L.off_mask) + lane * NP;
-  const int rowI = __mul24(rr, L.gi.pitch), rowJ = __mul24(rr, L.gj.pitch);
+  const int rowI = __mul24(rr, L.gi.pitch);
+  const uint8_t* rowJ0 = sJ + __mul24(rr, L.gj.pitch) + xx0;
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
   const int maxLevel = A.nlevels - 1;
@@ -504,11 +566,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       Iw[SEG] = 0;
       const float fa = px - (float)ipx, fb = py - (float)ipy;
       int iw00, iw01, iw10, iw11;
-      bilinear_weights(fa, fb, iw00, iw01, iw10, iw11);
-      iw00 = __builtin_amdgcn_readfirstlane(iw00);
-      iw01 = __builtin_amdgcn_readfirstlane(iw01);
-      iw10 = __builtin_amdgcn_readfirstlane(iw10);
-      iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+      bilinear_weights_uniform(fa, fb, iw00, iw01, iw10, iw11);
       const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
       const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
       unsigned int pm[NP];
@@ -638,10 +696,21 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       A11 = Asum[0] * FLT_SCALE;
       A12 = Asum[1] * FLT_SCALE;
       A22 = Asum[2] * FLT_SCALE;
-      D = A11 * A22 - A12 * A12;
-      const float minEig =
-          (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
-      if ((double)minEig < prm.min_eig_thr || D < 1.1920928955078125e-7f) {
+      const float P = A11 * A22;
+      D = P - A12 * A12;
+      // cv rejects the level when minEig < threshold or D < FLT_EPSILON.  lambda_min >= det / trace, so a
+      // determinant well above trace * threshold settles the first test without the square root and
+      // the division; the margins (1e-3 relative on the threshold, 1e-6 * trace^2 and 1e-6 * A11 * A22
+      // absolute, i.e. > 10 ulp of every float rounding in either evaluation) keep the shortcut on the
+      // safe side, and whatever it does not settle takes cv's own expression.
+      const float T = A11 + A22;
+      bool reject = D < 1.1920928955078125e-7f;
+      if (!reject && !(2.f * D >= T * (prm.min_eig_c1 + 1e-6f * T) + 1e-6f * P)) {
+        const float minEig =
+            (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * win * win);
+        reject = (double)minEig < prm.min_eig_thr;
+      }
+      if (reject) {
         if (level == 0) status = false;
         level_ok = false;
       }
@@ -675,17 +744,13 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           __syncthreads();
         }
         int iw00, iw01, iw10, iw11;
-        bilinear_weights(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
-        iw00 = __builtin_amdgcn_readfirstlane(iw00);
-        iw01 = __builtin_amdgcn_readfirstlane(iw01);
-        iw10 = __builtin_amdgcn_readfirstlane(iw10);
-        iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+        bilinear_weights_uniform(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
         int b1 = -cI1, b2 = -cI2;
         {
           unsigned int R0[NA], R1[NA];
-          const uint8_t* row0 = sJ + rowJ + (iny - jy0) * L.gj.pitch;
-          lds_stream<NA>(row0, xx0 + (inx - jx0), R0);
-          lds_stream<NA>(row0 + L.gj.pitch, xx0 + (inx - jx0), R1);
+          // rowJ0 = sJ + rr * pitch + xx0 per lane; the rest of the address is wave-uniform
+          const uint8_t* p0 = rowJ0 + ((iny - jy0) * L.gj.pitch + (inx - jx0));
+          lds_stream_at<NA>(p0, L.gj.pitch, R0, R1);
           const unsigned int V0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
           const unsigned int V1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
           int Jw[SEG + 1];
