@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef VSF_LK_WAVES
+#define VSF_LK_WAVES 5  // waves per SIMD the LK kernels are register-limited to (window <= 21)
+#endif
 #ifndef VSF_SUM_LDS
 #define VSF_SUM_LDS 1  // exact sums through the LDS atomic unit (0: DPP + v_readlane only)
 #endif
@@ -841,7 +844,7 @@ __device__ __forceinline__ void lk_init_masks(const LkParams& prm, uint8_t* smem
 // ref: FeatureTrackerLucasKanade.cpp:36-80 (forward, backward on the forward survivors, then
 // ||back - original||_2 <= threshold in double against the ORIGINAL double position).
 template <int SEG>
-__global__ __launch_bounds__(64, (SEG <= 8 ? 4 : 2)) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
+__global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
                                                    const int* __restrict__ n, int cap, int nstreams,
                                                    LkParams prm, float2* __restrict__ fwd,
                                                    uint8_t* __restrict__ flags) {
@@ -876,7 +879,7 @@ __global__ __launch_bounds__(64, (SEG <= 8 ? 4 : 2)) void lk_fb_kernel(PyrView P
 
 // plain cv::calcOpticalFlowPyrLK on a point list (parity tests): one wave per point
 template <int SEG>
-__global__ __launch_bounds__(64, (SEG <= 8 ? 4 : 2)) void lk_points_kernel(PyrView P, PyrView C, const float2* __restrict__ pts,
+__global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_points_kernel(PyrView P, PyrView C, const float2* __restrict__ pts,
                                                        int n, LkParams prm, float2* __restrict__ out,
                                                        uint8_t* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
