@@ -208,6 +208,82 @@ class Detector:
                                          mptr, mstride, *table._ptrs(), table.capacity)
 
 
+class _AnmsDetector(C.Structure):
+    _fields_ = [("max_feature_number", C.c_int32), ("min_feature_distance", C.c_double),
+                ("detection_feature_number", C.c_int32),
+                ("detection_min_feature_distance", C.c_double),
+                ("detection_quality_level", C.c_double), ("detection_block_size", C.c_int32),
+                ("detection_ignore_edge", C.c_int32), ("non_max_suppression_tolerance", C.c_double),
+                ("max_feature_index", C.c_uint64)]
+
+
+def circle_filled(img, cx, cy, radius, color=0):
+    """cv::circle(img, (cx, cy), radius, color, FILLED), in place."""
+    assert img.dtype == np.uint8 and img.flags["C_CONTIGUOUS"]
+    h, w = img.shape
+    lib().orc_circle_filled(img.ctypes.data_as(C.c_void_p), w, h, w, int(cx), int(cy), int(radius),
+                            C.c_uint8(color))
+    return img
+
+
+def circle_halfwidths(radius):
+    out = np.zeros(radius + 1, np.int32)
+    lib().orc_circle_halfwidths(int(radius), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def sort_idx_descending(keys):
+    keys = np.ascontiguousarray(keys, np.int32)
+    idx = np.zeros(len(keys), np.int32)
+    lib().orc_sort_idx_descending(keys.ctypes.data_as(C.c_void_p), len(keys),
+                                  idx.ctypes.data_as(C.c_void_p))
+    return idx
+
+
+def ssc(kxy, num_ret, tolerance, cols, rows):
+    kxy = np.ascontiguousarray(kxy, np.float32).reshape(-1, 2)
+    res = np.zeros(max(len(kxy), 1), np.int32)
+    n = lib().orc_ssc(kxy.ctypes.data_as(C.c_void_p), len(kxy), int(num_ret), C.c_float(tolerance),
+                      int(cols), int(rows), res.ctypes.data_as(C.c_void_p))
+    return res[:max(n, 0)].copy(), n
+
+
+class AnmsDetector:
+    """FeatureDetectorANMS (ref: FeatureDetectorANMS.cpp:13-212)."""
+
+    def __init__(self, max_features=300, min_distance=10.0, **kw):
+        self.s = _AnmsDetector()
+        lib().orc_anms_detector_init(C.byref(self.s), max_features, C.c_double(min_distance))
+        for k, v in kw.items():
+            setattr(self.s, k, v)
+
+    @property
+    def max_feature_index(self):
+        return int(self.s.max_feature_index)
+
+    def build_mask(self, w, h, xy, mask=None):
+        xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+        flag = np.zeros((h, w), np.uint8)
+        mptr, mstride = None, 0
+        if mask is not None:
+            mask = _img(mask)
+            mptr, mstride = mask.ctypes.data_as(C.c_void_p), mask.shape[1]
+        lib().orc_anms_build_mask(C.byref(self.s), w, h, mptr, mstride,
+                                  xy.ctypes.data_as(C.c_void_p), len(xy),
+                                  flag.ctypes.data_as(C.c_void_p))
+        return flag
+
+    def update_detection(self, table, img, mask=None):
+        img = _img(img)
+        h, w = img.shape
+        mptr, mstride = None, 0
+        if mask is not None:
+            mask = _img(mask)
+            mptr, mstride = mask.ctypes.data_as(C.c_void_p), mask.shape[1]
+        return lib().orc_anms_detector_update(C.byref(self.s), img.ctypes.data_as(C.c_void_p), w, h,
+                                              w, mptr, mstride, *table._ptrs(), table.capacity)
+
+
 class Tracker:
     """FeatureTrackerLucasKanade (ref: FeatureTrackerLucasKanade.cpp:8-240)."""
 

@@ -674,6 +674,364 @@ int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int s
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* reference wrapper: FeatureDetectorANMS (+ cv::circle, cv::sortIdx, anms::Ssc)               */
+/* ------------------------------------------------------------------------------------------ */
+/* cv: drawing.cpp Circle(), fill != 0.  Each step of the midpoint walk (dx from radius down, dy
+ * from 0 up, while dx >= dy) paints the rows cy-+dy over [cx-dx, cx+dx] and the rows cy-+dx over
+ * [cx-dy, cx+dy]; the clipped branch of the original paints the same spans cut to the image. */
+static void hline_clip(uint8_t* img, int w, int h, int stride, int y, int x1, int x2, uint8_t c) {
+  if (y < 0 || y >= h) return;
+  if (x1 < 0) x1 = 0;
+  if (x2 > w - 1) x2 = w - 1;
+  for (int x = x1; x <= x2; x++) img[(size_t)y * stride + x] = c;
+}
+
+void orc_circle_filled(uint8_t* img, int w, int h, int stride, int cx, int cy, int radius,
+                       uint8_t color) {
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  while (dx >= dy) {
+    hline_clip(img, w, h, stride, cy - dy, cx - dx, cx + dx, color);
+    hline_clip(img, w, h, stride, cy + dy, cx - dx, cx + dx, color);
+    hline_clip(img, w, h, stride, cy - dx, cx - dy, cx + dy, color);
+    hline_clip(img, w, h, stride, cy + dx, cx - dy, cx + dy, color);
+    dy++;
+    err += plus;
+    plus += 2;
+    const int mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+}
+
+int orc_circle_halfwidths(int radius, int* halfw) {
+  for (int i = 0; i <= radius; i++) halfw[i] = -1;
+  int err = 0, dx = radius, dy = 0, plus = 1, minus = (radius << 1) - 1;
+  while (dx >= dy) {
+    if (dx > halfw[dy]) halfw[dy] = dx;
+    if (dy > halfw[dx]) halfw[dx] = dy;
+    dy++;
+    err += plus;
+    plus += 2;
+    const int mask = (err <= 0) - 1;
+    err -= minus & mask;
+    dx += mask;
+    minus -= mask & 2;
+  }
+  return 0;
+}
+
+/* libstdc++ std::sort(first, last, comp) on an int index array with comp(a, b) = keys[a] < keys[b]
+ * (cv: LessThanIdx), restated from bits/stl_algo.h / bits/stl_heap.h. */
+typedef struct {
+  const int* keys;
+} idx_less;
+static inline int il(const idx_less* c, int a, int b) { return c->keys[a] < c->keys[b]; }
+static inline void iswap(int* a, int* b) {
+  const int t = *a;
+  *a = *b;
+  *b = t;
+}
+static void ss_push_heap(int* first, long hole, long top, int value, const idx_less* c) {
+  long parent = (hole - 1) / 2;
+  while (hole > top && il(c, first[parent], value)) {
+    first[hole] = first[parent];
+    hole = parent;
+    parent = (hole - 1) / 2;
+  }
+  first[hole] = value;
+}
+static void ss_adjust_heap(int* first, long hole, long len, int value, const idx_less* c) {
+  const long top = hole;
+  long child = hole;
+  while (child < (len - 1) / 2) {
+    child = 2 * (child + 1);
+    if (il(c, first[child], first[child - 1])) child--;
+    first[hole] = first[child];
+    hole = child;
+  }
+  if ((len & 1) == 0 && child == (len - 2) / 2) {
+    child = 2 * (child + 1);
+    first[hole] = first[child - 1];
+    hole = child - 1;
+  }
+  ss_push_heap(first, hole, top, value, c);
+}
+static void ss_make_heap(int* first, int* last, const idx_less* c) {
+  const long len = last - first;
+  if (len < 2) return;
+  long parent = (len - 2) / 2;
+  for (;;) {
+    ss_adjust_heap(first, parent, len, first[parent], c);
+    if (parent == 0) return;
+    parent--;
+  }
+}
+static void ss_pop_heap(int* first, int* last, int* result, const idx_less* c) {
+  const int value = *result;
+  *result = *first;
+  ss_adjust_heap(first, 0, last - first, value, c);
+}
+static void ss_partial_sort_all(int* first, int* last, const idx_less* c) { /* middle == last */
+  ss_make_heap(first, last, c);
+  while (last - first > 1) {
+    --last;
+    ss_pop_heap(first, last, last, c);
+  }
+}
+static void ss_move_median_to_first(int* result, int* a, int* b, int* cc, const idx_less* c) {
+  if (il(c, *a, *b)) {
+    if (il(c, *b, *cc))
+      iswap(result, b);
+    else if (il(c, *a, *cc))
+      iswap(result, cc);
+    else
+      iswap(result, a);
+  } else if (il(c, *a, *cc))
+    iswap(result, a);
+  else if (il(c, *b, *cc))
+    iswap(result, cc);
+  else
+    iswap(result, b);
+}
+static int* ss_unguarded_partition(int* first, int* last, int* pivot, const idx_less* c) {
+  for (;;) {
+    while (il(c, *first, *pivot)) ++first;
+    --last;
+    while (il(c, *pivot, *last)) --last;
+    if (!(first < last)) return first;
+    iswap(first, last);
+    ++first;
+  }
+}
+static void ss_introsort_loop(int* first, int* last, long depth, const idx_less* c) {
+  while (last - first > 16) {
+    if (depth == 0) {
+      ss_partial_sort_all(first, last, c);
+      return;
+    }
+    --depth;
+    int* mid = first + (last - first) / 2;
+    ss_move_median_to_first(first, first + 1, mid, last - 1, c);
+    int* cut = ss_unguarded_partition(first + 1, last, first, c);
+    ss_introsort_loop(cut, last, depth, c);
+    last = cut;
+  }
+}
+static void ss_unguarded_linear_insert(int* last, const idx_less* c) {
+  const int val = *last;
+  int* next = last - 1;
+  while (il(c, val, *next)) {
+    *last = *next;
+    last = next;
+    --next;
+  }
+  *last = val;
+}
+static void ss_insertion_sort(int* first, int* last, const idx_less* c) {
+  if (first == last) return;
+  for (int* i = first + 1; i != last; ++i) {
+    if (il(c, *i, *first)) {
+      const int val = *i;
+      memmove(first + 1, first, (size_t)(i - first) * sizeof(int));
+      *first = val;
+    } else
+      ss_unguarded_linear_insert(i, c);
+  }
+}
+static void ss_sort(int* first, int* last, const idx_less* c) {
+  if (first == last) return;
+  long n = last - first, lg = 0;
+  while (n > 1) { /* std::__lg */
+    n >>= 1;
+    lg++;
+  }
+  ss_introsort_loop(first, last, lg * 2, c);
+  if (last - first > 16) {
+    ss_insertion_sort(first, first + 16, c);
+    for (int* i = first + 16; i != last; ++i) ss_unguarded_linear_insert(i, c);
+  } else
+    ss_insertion_sort(first, last, c);
+}
+
+/* cv: sort.cpp sortIdx_<int>, one row, CV_SORT_DESCENDING -- SURVEY A.5 */
+void orc_sort_idx_descending(const int* keys, int n, int* idx) {
+  idx_less c = {keys};
+  for (int j = 0; j < n; j++) idx[j] = j;
+  ss_sort(idx, idx + n, &c);
+  for (int j = 0; j < n / 2; j++) iswap(&idx[j], &idx[n - 1 - j]);
+}
+
+/* ref: NonMaximumSuppression/anms/anms.cpp:344-438 */
+int orc_ssc(const float* kxy, int n, int num_ret, float tolerance, int cols, int rows, int* result) {
+  if (num_ret <= 0) return -1;
+  const int exp1 = rows + cols + 2 * num_ret; /* :350 */
+  const long long exp2 = ((long long)4 * cols + (long long)4 * num_ret + (long long)4 * rows * num_ret +
+                          (long long)rows * rows + (long long)cols * cols - (long long)2 * rows * cols +
+                          (long long)4 * rows * cols * num_ret);
+  const double exp3 = sqrt((double)exp2);
+  const double exp4 = num_ret - 1;
+  const double sol1 = -round((exp1 + exp3) / exp4); /* :359-360 */
+  const double sol2 = -round((exp1 - exp3) / exp4);
+  int high = (int)((sol1 > sol2) ? sol1 : sol2);   /* :362-365 */
+  int low = (int)floor(sqrt((double)n / num_ret)); /* :366 */
+  int width, prev_width = -1;
+  const unsigned int K = (unsigned int)num_ret;
+  /* :374-375  K - (K * tolerance): unsigned * float -> float arithmetic */
+  const unsigned int Kmin = (unsigned int)roundf((float)K - ((float)K * tolerance));
+  const unsigned int Kmax = (unsigned int)roundf((float)K + ((float)K * tolerance));
+  int nres = 0, nfinal = 0;
+  int* res = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  for (;;) {
+    width = low + (high - low) / 2; /* :380 */
+    if (width == prev_width || low > high) { /* :381-386 previous iteration's result */
+      nfinal = nres;
+      memcpy(result, res, sizeof(int) * (size_t)nres);
+      break;
+    }
+    nres = 0;
+    const double c = (double)width / 2.0; /* :388 */
+    const int ncc = (int)floor(cols / c), ncr = (int)floor(rows / c);
+    uint8_t* cov = (uint8_t*)calloc((size_t)(ncr + 1) * (ncc + 1), 1);
+    const int reach = (int)floor(width / c);
+    for (int i = 0; i < n; i++) {
+      const int row = (int)floor(kxy[2 * i + 1] / c), col = (int)floor(kxy[2 * i] / c);
+      if (!cov[(size_t)row * (ncc + 1) + col]) {
+        res[nres++] = i;
+        const int r0 = row - reach >= 0 ? row - reach : 0, r1 = row + reach <= ncr ? row + reach : ncr;
+        const int c0 = col - reach >= 0 ? col - reach : 0, c1 = col + reach <= ncc ? col + reach : ncc;
+        for (int rr = r0; rr <= r1; rr++)
+          for (int cc = c0; cc <= c1; cc++) cov[(size_t)rr * (ncc + 1) + cc] = 1;
+      }
+    }
+    free(cov);
+    if ((unsigned int)nres >= Kmin && (unsigned int)nres <= Kmax) { /* :423-425 */
+      nfinal = nres;
+      memcpy(result, res, sizeof(int) * (size_t)nres);
+      break;
+    } else if ((unsigned int)nres < Kmin)
+      high = width - 1;
+    else
+      low = width + 1;
+    prev_width = width;
+  }
+  free(res);
+  return nfinal;
+}
+
+/* ref: FeatureDetectorANMS.cpp:13-35 (Parameter defaults) and :37-53 (ctor) */
+void orc_anms_detector_init(orc_anms_detector* d, int32_t max_features, double min_distance) {
+  d->max_feature_number = max_features;
+  d->min_feature_distance = min_distance;
+  d->detection_feature_number = max_features * 2;
+  d->detection_min_feature_distance = 1.0;
+  d->detection_quality_level = 0.001;
+  d->detection_block_size = 4;
+  d->detection_ignore_edge = 20;
+  d->non_max_suppression_tolerance = 0.1;
+  d->max_feature_index = 0;
+}
+
+/* ref: FeatureDetectorANMS.cpp:107-132 */
+void orc_anms_build_mask(const orc_anms_detector* d, int w, int h, const uint8_t* mask,
+                         int mask_stride, const double* xy, int n, uint8_t* flag) {
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) flag[(size_t)y * w + x] = mask ? mask[(size_t)y * mask_stride + x] : 1;
+  const int radius = (int)d->min_feature_distance; /* :127 static_cast<int> */
+  for (int i = 0; i < n; i++) {
+    const double px = xy[2 * i], py = xy[2 * i + 1];
+    if (px > 0 && px < w && py > 0 && py < h) /* :123-124 */
+      orc_circle_filled(flag, w, h, w, (int)px, (int)py, radius, 0); /* cv::Point(double,double): truncation */
+  }
+  /* :107-113 edge_mask: cv::rectangle(Rect(e, e, w-2e, h-2e), 1, FILLED) covers [e, w-e-1] x [e, h-e-1]
+   * (nothing when the rectangle is empty); :132 bitwise_and -- BITWISE, so only bit 0 of the mask survives */
+  const int e = d->detection_ignore_edge;
+  const int ew = w - 2 * e, eh = h - 2 * e;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) {
+      int em = 0;
+      if (ew > 0 && eh > 0) {
+        /* cv::rectangle clips to the image; with e < 0 the whole image is covered */
+        em = (x >= e && x <= e + ew - 1 && y >= e && y <= e + eh - 1) ? 1 : 0;
+      }
+      flag[(size_t)y * w + x] &= (uint8_t)em;
+    }
+}
+
+/* ref: FeatureDetectorANMS.cpp:69-212 */
+int orc_anms_detector_update(orc_anms_detector* d, const uint8_t* img, int w, int h, int stride,
+                             const uint8_t* mask, int mask_stride, uint64_t* ids, double* xy,
+                             uint32_t* age, int* n_inout, int capacity) {
+  const int n0 = *n_inout;
+  int n = n0, rc = 0;
+  uint8_t* flag = (uint8_t*)malloc((size_t)w * h);
+  orc_anms_build_mask(d, w, h, mask, mask_stride, xy, n0, flag);
+  /* :135-137 GFTTDetector::detect = goodFeaturesToTrack(nfeatures, quality, minDistance, mask, blockSize);
+   * KeyPoint(pt, blockSize): response stays 0 (Q9) */
+  const int kcap = d->detection_feature_number > 0 ? d->detection_feature_number : w * h;
+  float* kp = (float*)malloc(sizeof(float) * 2 * (size_t)kcap);
+  const int ndet = orc_good_features_to_track(img, w, h, stride, 0, 0, w, h, d->detection_feature_number,
+                                              d->detection_quality_level, d->detection_min_feature_distance,
+                                              flag, w, d->detection_block_size, kp, kcap);
+  int need = d->max_feature_number - n0; /* :174-175 */
+  if (need < 0) need = 0;
+  int* sel = (int*)malloc(sizeof(int) * (size_t)(ndet > 0 ? ndet : 1));
+  float* sorted = (float*)malloc(sizeof(float) * 2 * (size_t)(ndet > 0 ? ndet : 1));
+  int nsel = 0;
+  const float* out_pts = kp;
+  if (need < ndet) { /* :177-183 suppressNonMax */
+    if (need == 0) {
+      rc = 1; /* Ssc(numRetPoints = 0): undefined in the reference; nothing is added here */
+      nsel = 0;
+    } else {
+      /* NonMaximumSuppression.cpp:43-53: int-truncated responses (all 0), sortIdx descending */
+      int* keys = (int*)calloc((size_t)ndet, sizeof(int));
+      int* idx = (int*)malloc(sizeof(int) * (size_t)ndet);
+      orc_sort_idx_descending(keys, ndet, idx);
+      for (int i = 0; i < ndet; i++) {
+        sorted[2 * i] = kp[2 * idx[i]];
+        sorted[2 * i + 1] = kp[2 * idx[i] + 1];
+      }
+      nsel = orc_ssc(sorted, ndet, need, (float)d->non_max_suppression_tolerance, w, h, sel);
+      out_pts = sorted;
+      free(keys);
+      free(idx);
+    }
+  } else { /* :184-186 */
+    nsel = ndet;
+    for (int i = 0; i < ndet; i++) sel[i] = i;
+  }
+  uint64_t feature_index = d->max_feature_index + 1; /* :198 */
+  for (int k = 0; k < nsel; k++) {
+    int slot = -1;
+    for (int i = 0; i < n; i++)
+      if (ids[i] == feature_index) {
+        slot = i;
+        break;
+      }
+    if (slot < 0) {
+      if (n >= capacity) {
+        rc = -1;
+        break;
+      }
+      slot = n++;
+    }
+    ids[slot] = feature_index;
+    xy[2 * slot] = (double)out_pts[2 * sel[k]];
+    xy[2 * slot + 1] = (double)out_pts[2 * sel[k] + 1];
+    age[slot] = 1;
+    feature_index++;
+  }
+  d->max_feature_index = feature_index - 1; /* :211 */
+  *n_inout = n;
+  free(sorted);
+  free(sel);
+  free(kp);
+  free(flag);
+  return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* reference wrapper: FeatureTrackerLucasKanade                                                */
 /* ------------------------------------------------------------------------------------------ */
 /* ref: src/vslam/feature/FeatureTrackerLucasKanade.cpp:8-23 */

@@ -112,6 +112,48 @@ int orc_tracker_track_pair(const orc_tracker* t, const uint8_t* prev, int prev_s
                            const uint8_t* cur, int cur_stride, int w, int h, uint64_t* ids,
                            double* xy, uint32_t* age, int* n_inout, orc_track_stats* stats);
 
+/* ---- ANMS detector (ref: src/vslam/feature/FeatureDetectorANMS.cpp) ---- */
+/* cv::circle(img, center, radius, color, FILLED) for 8-bit single-channel images, thickness < 0,
+ * LINE_8, shift 0 -- OpenCV 3.4 drawing.cpp Circle() (midpoint algorithm, horizontal spans). */
+void orc_circle_filled(uint8_t* img, int w, int h, int stride, int cx, int cy, int radius,
+                       uint8_t color);
+/* Half-width of that disc on the rows cy +- d, d = 0..radius: the disc is { |dy| <= radius,
+ * |dx| <= halfw[|dy|] }.  Returns 0. */
+int orc_circle_halfwidths(int radius, int* halfw /* radius+1 */);
+/* cv::sortIdx(std::vector<int>, idx, CV_SORT_DESCENDING): idx = iota; std::sort(idx, LessThanIdx);
+ * reverse.  std::sort restated from libstdc++ (introsort: median-of-3 to first, unguarded partition,
+ * heapsort fallback, final insertion sort); NOT stable, so equal keys come out permuted (Q9). */
+void orc_sort_idx_descending(const int* keys, int n, int* idx);
+/* anms::Ssc (NonMaximumSuppression/anms/anms.cpp:344-438) on keypoints given in sweep order.
+ * result receives indices into kxy; returns their number, or -1 when num_ret <= 0 (the reference
+ * divides by zero there: undefined). */
+int orc_ssc(const float* kxy, int n, int num_ret, float tolerance, int cols, int rows, int* result);
+
+typedef struct {
+  int32_t max_feature_number;             /* Parameter::max_feature_number_            :17 */
+  double min_feature_distance;            /* min_feature_distance_                     :18 */
+  int32_t detection_feature_number;       /* detection_feature_number_ = 2 * max       :23 */
+  double detection_min_feature_distance;  /* 1.0                                       :24 */
+  double detection_quality_level;         /* 0.001                                     :25 */
+  int32_t detection_block_size;           /* 4                                         :26 */
+  int32_t detection_ignore_edge;          /* 20                                        :29 */
+  double non_max_suppression_tolerance;   /* 0.1                                       :34 */
+  uint64_t max_feature_index;             /* member, starts at 0                       :39 */
+} orc_anms_detector;
+
+void orc_anms_detector_init(orc_anms_detector* d, int32_t max_features, double min_distance);
+/* The mask GFTT sees (FeatureDetectorANMS.cpp:107-132): user mask (or ones), discs zeroed at the
+ * existing in-image features, AND-ed bitwise with the edge rectangle of ones. */
+void orc_anms_build_mask(const orc_anms_detector* d, int w, int h, const uint8_t* mask,
+                         int mask_stride, const double* xy, int n, uint8_t* flag /* w*h */);
+/* FeatureDetectorANMS::Detect (:69-212).  Returns 0, -1 when capacity is exhausted.  When the
+ * database already holds max_feature_number entries and corners are detected the reference calls
+ * Ssc with numRetPoints = 0 (undefined behaviour); this restatement adds nothing then and
+ * returns 1. */
+int orc_anms_detector_update(orc_anms_detector* d, const uint8_t* img, int w, int h, int stride,
+                             const uint8_t* mask, int mask_stride, uint64_t* ids, double* xy,
+                             uint32_t* age, int* n_inout, int capacity);
+
 /* One frontend step on `streams` independent streams, used as the timed CPU baseline:
  * track (3-arg) then detect on the same frame.  Parallel over streams with OpenMP when built
  * with -fopenmp (threads = omp default), serial otherwise. */
