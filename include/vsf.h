@@ -60,7 +60,22 @@ typedef struct vsf_params {
   int32_t streams;        /* independent streams held by this context (>= 1) */
   int32_t capacity;       /* feature-table capacity per stream; 0 = max_features + 64 */
   int32_t device_id;      /* HIP device ordinal */
+  /* Which FeatureDetectorBase implementation vsf_detect / vsf_batch_detect / vsf_batch_step run:
+   * VSF_DETECTOR_BUCKETING = FeatureDetectorShiTomasiBucketing (fields above),
+   * VSF_DETECTOR_ANMS      = FeatureDetectorANMS (FeatureDetectorANMS.cpp:13-212): max_features and
+   * min_distance above are its Parameter::max_feature_number_ / min_feature_distance_ (:17-18; the disc
+   * radius is int(min_distance) <= 31); the fields below are the rest of its Parameter (:23-34).
+   * detection_min_feature_distance_ is fixed at the reference's 1.0 and Harris is off (:24,27). */
+  int32_t detector_kind;
+  int32_t anms_detection_features; /* detection_feature_number_; 0 = 2 * max_features (:23); <= 2048 */
+  double anms_quality_level;       /* detection_quality_level_ 0.001 (:25) */
+  int32_t anms_block_size;         /* detection_block_size_ 4 (:26); 3 or 4 */
+  int32_t anms_ignore_edge;        /* detection_ignore_edge_ 20 (:29) */
+  double anms_tolerance;           /* non_max_suppression_tolerance_ 0.1 (:34) */
 } vsf_params;
+
+#define VSF_DETECTOR_BUCKETING 0
+#define VSF_DETECTOR_ANMS 1
 
 /* The three counts FeatureTrackerLucasKanade::Track logs (FeatureTrackerLucasKanade.cpp:87-104). */
 typedef struct vsf_track_stats {
@@ -149,6 +164,11 @@ int vsf_debug_lk(vsf_ctx* ctx, const uint8_t* prev, const uint8_t* next, int32_t
  * [cell_h][cell_w] map (at most w*h floats), rect (may be NULL) the cell's x, y, w, h. */
 int vsf_debug_min_eig(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
                       int32_t cell, float* out, int32_t* rect);
+
+/* Intermediates of the last vsf_detect / vsf_batch_detect of an ANMS context, for one stream: the mask
+ * cv::GFTTDetector saw (FeatureDetectorANMS.cpp:107-132; [h][w] bytes, may be NULL) and the detected
+ * keypoints in cv order as x, y int16 pairs (kp may be NULL; at most anms_detection_features pairs). */
+int vsf_debug_anms(vsf_ctx* ctx, int32_t stream, uint8_t* flag_out, int16_t* kp_out, int32_t* n_kp_out);
 
 /* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py ---- */
 #define VSF_K_PYRAMID 0

@@ -26,7 +26,7 @@ ABI_SYMBOLS = [
     "vsf_set_max_feature_index", "vsf_batch_track", "vsf_batch_detect", "vsf_batch_step",
     "vsf_batch_upload", "vsf_batch_download", "vsf_batch_device_tables", "vsf_batch_status",
     "vsf_batch_export_tracks",
-    "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig",
+    "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig", "vsf_debug_anms",
     "vsf_profile_enable", "vsf_profile_read",
 ]
 
@@ -39,7 +39,14 @@ class VsfParams(C.Structure):
         ("klt_max_level", C.c_int32), ("min_eig_thr", C.c_double), ("backtrack_thr", C.c_double),
         ("width", C.c_int32), ("height", C.c_int32), ("streams", C.c_int32),
         ("capacity", C.c_int32), ("device_id", C.c_int32),
+        ("detector_kind", C.c_int32), ("anms_detection_features", C.c_int32),
+        ("anms_quality_level", C.c_double), ("anms_block_size", C.c_int32),
+        ("anms_ignore_edge", C.c_int32), ("anms_tolerance", C.c_double),
     ]
+
+
+DETECTOR_BUCKETING = 0
+DETECTOR_ANMS = 1
 
 
 class VsfTrackStats(C.Structure):
@@ -106,7 +113,9 @@ class Context:
             raise VsfError(rc, "vsf_create failed (no GPU / bad parameters)")
         self.streams = params.streams
         self.width, self.height = params.width, params.height
-        self.capacity = params.capacity if params.capacity > 0 else params.max_features + 64
+        cap = C.c_int32()  # the library's own answer (the default depends on the detector kind)
+        self._chk(lib().vsf_batch_device_tables(self._h, None, None, None, None, C.byref(cap)))
+        self.capacity = cap.value
 
     def close(self):
         if getattr(self, "_h", None):
@@ -250,6 +259,15 @@ class Context:
         rx, ry, rw, rh = [int(v) for v in rect]
         return out[:rw * rh].reshape(rh, rw).copy(), (rx, ry, rw, rh)
 
+    def debug_anms(self, stream=0):
+        """(mask GFTT saw [h][w], detected keypoints [n][2] in cv order) of the last ANMS detection."""
+        w, h = self.params.width, self.params.height
+        flag = np.zeros((h, w), np.uint8)
+        kp = np.zeros((4096, 2), np.int16)
+        n = C.c_int32(0)
+        self._chk(lib().vsf_debug_anms(self._h, stream, _vp(flag), _vp(kp), C.byref(n)))
+        return flag, kp[:n.value].copy()
+
     # ---- profiling ----
     def profile_enable(self, on=True):
         self._chk(lib().vsf_profile_enable(self._h, 1 if on else 0))
@@ -292,6 +310,45 @@ class FeatureDetectorShiTomasiBucketing:
         p = default_params(grid_rows=division_number_row, grid_cols=division_number_col,
                            max_features=max_feature_number, min_distance=min_feature_distance,
                            width=width, height=height, device_id=device_id, capacity=capacity)
+        self.ctx = Context(p)
+
+    def UpdateDetection(self, db, current_image, mask_image=None):
+        db.n = self.ctx.detect(current_image, db.ids, db.xy, db.age, db.n, mask_image)
+
+    @property
+    def max_feature_index_(self):
+        return self.ctx.get_max_feature_index()
+
+
+class FeatureDetectorANMS:
+    """Mirror of vslam::feature::FeatureDetectorANMS (ref: FeatureDetectorANMS.hpp / .cpp:13-67):
+    Parameter fields by their reference names, UpdateDetection."""
+
+    class Parameter:
+        def __init__(self):  # FeatureDetectorANMS.cpp:13-35
+            self.max_feature_number_ = 300
+            self.min_feature_distance_ = 10.0
+            self.detection_feature_number_ = self.max_feature_number_ * 2
+            self.detection_min_feature_distance_ = 1.0
+            self.detection_quality_level_ = 0.001
+            self.detection_block_size_ = 4
+            self.detection_use_harris_corner_ = False
+            self.detection_k_ = 0.04
+            self.detection_ignore_edge_ = 20
+            self.non_max_suppression_tolerance_ = 0.1
+
+    def __init__(self, parameter, width, height, device_id=0, capacity=0):
+        if parameter.detection_use_harris_corner_ or parameter.detection_min_feature_distance_ != 1.0:
+            raise VsfError(-1, "Harris scoring / detection_min_feature_distance_ != 1.0 are not supported")
+        p = default_params(detector_kind=DETECTOR_ANMS, max_features=parameter.max_feature_number_,
+                           min_distance=parameter.min_feature_distance_,
+                           anms_detection_features=parameter.detection_feature_number_,
+                           anms_quality_level=parameter.detection_quality_level_,
+                           anms_block_size=parameter.detection_block_size_,
+                           anms_ignore_edge=parameter.detection_ignore_edge_,
+                           anms_tolerance=parameter.non_max_suppression_tolerance_,
+                           width=width, height=height, device_id=device_id, capacity=capacity)
+        self.parameter_ = parameter
         self.ctx = Context(p)
 
     def UpdateDetection(self, db, current_image, mask_image=None):

@@ -1,0 +1,409 @@
+// vsf_anms.hpp -- FeatureDetectorANMS on the device (ref: src/vslam/feature/FeatureDetectorANMS.cpp:69-212):
+//   mask  = (user mask or ones) with a cv::circle disc zeroed at every in-image feature, AND the edge
+//           rectangle of ones (:107-132)
+//   GFTT  = cv::GFTTDetector(nfeatures, quality 0.001, minDistance 1, blockSize 4) on the whole frame:
+//           score_kernel<4> + candidate_kernel with the frame as one cell, then the nfeatures largest
+//           keys in cv's greaterThanPtr order (minDistance 1 never rejects distinct pixels)
+//   ANMS  = the reference's degenerate cv::sortIdx permutation (Q9) followed by anms::Ssc
+//           (NonMaximumSuppression.cpp:43-53, anms/anms.cpp:344-438)
+//   ids   = max_feature_index + 1 ... (:198-211), through append_kernel with id_bias = 1.
+// Included by vsf_kernels.hpp (inside no namespace).
+#pragma once
+
+namespace vsf {
+
+constexpr int ANMS_MAX_RADIUS = 31;
+
+struct AnmsParams {
+  int w, h;
+  int max_features;  // Parameter::max_feature_number_
+  int radius;        // static_cast<int>(min_feature_distance)  (:127)
+  int edge;          // detection_ignore_edge_
+  int nfeatures;     // detection_feature_number_
+  float tolerance;   // non_max_suppression_tolerance_ as float (:181)
+  int kcap;          // power of two >= nfeatures (sort / LDS array size)
+  int hash_size;     // power of two >= 2 * kcap
+  int hash_bits;
+  int cand_cap;      // candidate keys kept per stream
+  double quality;    // detection_quality_level_
+  int halfw[ANMS_MAX_RADIUS + 1];  // cv::Circle half widths: disc = { |dy| <= r, |dx| <= halfw[|dy|] }
+};
+
+// (user mask & 1) inside the edge rectangle, 0 outside; one thread per pixel quad of a row.
+__global__ __launch_bounds__(256) void anms_mask_kernel(const uint8_t* __restrict__ masks, long long mask_sstride,
+                                                        int mask_row_stride, AnmsParams ap,
+                                                        uint8_t* __restrict__ flag) {
+  const int stream = blockIdx.z, y = blockIdx.y;
+  const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (x0 >= ap.w) return;
+  const int ew = ap.w - 2 * ap.edge, eh = ap.h - 2 * ap.edge;
+  const bool yin = ew > 0 && eh > 0 && y >= ap.edge && y <= ap.edge + eh - 1;
+  const uint8_t* M = masks ? masks + (long long)stream * mask_sstride + (long long)y * mask_row_stride : nullptr;
+  uint8_t* F = flag + ((long long)stream * ap.h + y) * ap.w;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int x = x0 + b;
+    if (x < ap.w) {
+      uint8_t v = 0;
+      if (yin && x >= ap.edge && x <= ap.edge + ew - 1) v = M ? (uint8_t)(M[x] & 1u) : (uint8_t)1;  // :132 bitwise_and
+      F[x] = v;
+    }
+  }
+}
+
+// Zeroes the cv::circle disc of every in-image feature (:122-131) and resets the per-stream counters.
+__global__ __launch_bounds__(256) void anms_disc_kernel(const double2* __restrict__ xy, const int* __restrict__ n,
+                                                        int cap, AnmsParams ap, uint8_t* __restrict__ flag,
+                                                        unsigned int* __restrict__ cell_max,
+                                                        int* __restrict__ cand_cnt) {
+  const int stream = blockIdx.x;
+  const int n0 = n[stream];
+  const int rows = 2 * ap.radius + 1;
+  uint8_t* F = flag + (long long)stream * ap.h * ap.w;
+  for (int t = threadIdx.x; t < n0 * rows; t += 256) {
+    const int f = t / rows, dy = t - f * rows - ap.radius;
+    const double2 p = xy[(long long)stream * cap + f];
+    if (p.x > 0 && p.x < (double)ap.w && p.y > 0 && p.y < (double)ap.h) {  // :123-124
+      const int cx = (int)p.x, cy = (int)p.y;                              // cv::Point(double, double)
+      const int y = cy + dy;
+      if (y >= 0 && y < ap.h) {
+        const int hw = ap.halfw[dy < 0 ? -dy : dy];
+        const int x1 = max(cx - hw, 0), x2 = min(cx + hw, ap.w - 1);
+        for (int x = x1; x <= x2; x++) F[(long long)y * ap.w + x] = 0;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    cell_max[stream] = 0u;
+    cand_cnt[stream] = 0;
+  }
+}
+
+// Candidate key of raster position idx straight from the lambda map (used when the candidate list
+// overflowed): threshold, 3x3 local maximum, interior only, mask -- SURVEY A.1 steps 5-6.
+__device__ __forceinline__ unsigned long long anms_key_from_map(const float* __restrict__ L, int w, int h, float thr,
+                                                                const uint8_t* __restrict__ M, int idx) {
+  const int y = idx / w, x = idx - y * w;
+  if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return 0ull;
+  float v = L[idx];
+  v = v > thr ? v : 0.f;
+  if (v == 0.f) return 0ull;
+  float m = v;
+#pragma unroll
+  for (int j = -1; j <= 1; j++)
+#pragma unroll
+    for (int q = -1; q <= 1; q++) {
+      float t = L[idx + j * w + q];
+      t = t > thr ? t : 0.f;
+      m = fmaxf(m, t);
+    }
+  if (v != m || !M[idx]) return 0ull;
+  return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)idx;
+}
+
+// The nfeatures largest candidate keys of a stream, in descending order (= cv's sorted corner list cut
+// at maxCorners).  MSB-first radix select (8 passes of 8 bits) finds the K-th largest key, the keys at
+// or above it are gathered into LDS and sorted there (bitonic, descending).  One block per stream.
+__global__ __launch_bounds__(256) void anms_topk_kernel(const float* __restrict__ lam, long long lam_sstride,
+                                                        const uint8_t* __restrict__ flag,
+                                                        const unsigned int* __restrict__ cell_max,
+                                                        const unsigned long long* __restrict__ cand,
+                                                        const int* __restrict__ cand_cnt, AnmsParams ap,
+                                                        short2* __restrict__ kp, int* __restrict__ ndet) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);  // [kcap]
+  __shared__ unsigned int s_hist[256];
+  __shared__ unsigned long long s_prefix;
+  __shared__ int s_remaining, s_count;
+  const int stream = blockIdx.x;
+  const int total = cand_cnt[stream];
+  const bool overflow = total > ap.cand_cap;
+  const int M = overflow ? ap.w * ap.h : total;
+  const float* L = lam + (long long)stream * lam_sstride;
+  const uint8_t* F = flag + (long long)stream * ap.w * ap.h;
+  const unsigned long long* C = cand + (long long)stream * ap.cand_cap;
+  const unsigned int enc = cell_max[stream];
+  const float thr = (float)((enc ? (double)float_order_decode(enc) : 0.0) * ap.quality);
+  auto key_at = [&](int i) -> unsigned long long { return overflow ? anms_key_from_map(L, ap.w, ap.h, thr, F, i) : C[i]; };
+
+  // number of candidates (the list length, or a count over the map)
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  if (overflow) {
+    int c = 0;
+    for (int i = threadIdx.x; i < M; i += 256) c += key_at(i) != 0ull;
+    atomicAdd(&s_count, c);
+  } else if (threadIdx.x == 0) {
+    s_count = total;
+  }
+  __syncthreads();
+  const int ncand = s_count;
+  const int K = min(ncand, ap.nfeatures);
+  unsigned long long T = 1ull;  // keys are never 0
+  if (ncand > K) {
+    if (threadIdx.x == 0) {
+      s_prefix = 0ull;
+      s_remaining = K;
+    }
+    unsigned long long himask = 0ull;
+    for (int b = 7; b >= 0; b--) {
+      s_hist[threadIdx.x] = 0u;
+      __syncthreads();
+      const unsigned long long prefix = s_prefix;
+      for (int i = threadIdx.x; i < M; i += 256) {
+        const unsigned long long k = key_at(i);
+        if (k != 0ull && (k & himask) == prefix) atomicAdd(&s_hist[(unsigned int)(k >> (8 * b)) & 255u], 1u);
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        int rem = s_remaining, bin = 255;
+        for (; bin > 0; bin--) {
+          const int hcnt = (int)s_hist[bin];
+          if (hcnt >= rem) break;
+          rem -= hcnt;
+        }
+        s_prefix = prefix | ((unsigned long long)bin << (8 * b));
+        s_remaining = rem;
+      }
+      himask |= 0xffull << (8 * b);
+      __syncthreads();
+    }
+    T = s_prefix;
+  }
+  // gather and sort
+  __syncthreads();
+  for (int i = threadIdx.x; i < ap.kcap; i += 256) s_key[i] = 0ull;
+  if (threadIdx.x == 0) s_count = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < M; i += 256) {
+    const unsigned long long k = key_at(i);
+    if (k != 0ull && k >= T) {
+      const int slot = atomicAdd(&s_count, 1);
+      if (slot < ap.kcap) s_key[slot] = k;
+    }
+  }
+  __syncthreads();
+  for (int size = 2; size <= ap.kcap; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = threadIdx.x; i < ap.kcap / 2; i += 256) {
+        const int lo = ((i / stride) * stride * 2) + (i % stride), hi = lo + stride;
+        const bool desc = ((lo & size) == 0);
+        const unsigned long long a = s_key[lo], b2 = s_key[hi];
+        if (desc ? (a < b2) : (a > b2)) {
+          s_key[lo] = b2;
+          s_key[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  short2* out = kp + (long long)stream * ap.kcap;
+  for (int i = threadIdx.x; i < K; i += 256) {
+    const int idx = (int)(unsigned int)s_key[i];
+    const int y = idx / ap.w;
+    out[i] = make_short2((short)(idx - y * ap.w), (short)y);
+  }
+  if (threadIdx.x == 0) ndet[stream] = K;
+}
+
+// Position, before libstdc++'s std::sort, of the element std::sort leaves at position p when every
+// comparison is false (all keys equal, Q9).  introsort: while a segment is longer than 16, swap its
+// first and middle element, then the unguarded partition reverses [first + 1, last) and returns its
+// middle; recurse right, loop left; the final insertion sort moves nothing.  The segment tree depends
+// on n only, so the source is found by walking the path of p and undoing the transforms leaf to root.
+__device__ __forceinline__ int introsort_equal_src(int n, int p) {
+  int segf[32], segl[32], d = 0;
+  int first = 0, last = n;
+  while (last - first > 16) {
+    segf[d] = first;
+    segl[d] = last;
+    d++;
+    const int cut = first + 1 + (last - first - 1) / 2;
+    if (p >= cut)
+      first = cut;
+    else
+      last = cut;
+  }
+  int q = p;
+  for (int k = d - 1; k >= 0; k--) {
+    const int f = segf[k], l = segl[k], mid = f + (l - f) / 2;
+    if (q == f) {
+      q = mid;
+    } else {
+      const int x = f + l - q;
+      q = (x == mid) ? f : x;
+    }
+  }
+  return q;
+}
+
+// suppressNonMax + anms::Ssc + the need / detected branches of FeatureDetectorANMS::Detect (:174-186).
+// One block per stream.  The sweep "accept a keypoint iff its cell is uncovered, then cover the cells
+// within +-2" is sequential in the reference; here only the FIRST keypoint of a cell can ever be
+// accepted, and among those owners the accepted set is the greedy independent set in index order for
+// the relation |d_row| <= 2 && |d_col| <= 2, which is reached by rounds: an owner turns REJECTED when an
+// earlier conflicting owner is ACCEPTED, ACCEPTED when all earlier conflicting owners are REJECTED.
+// Cells: row = floor(y / (w/2)) = (2 y) / w in integers (y, w integers, w >= 1), likewise col.
+__global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict__ kp, const int* __restrict__ ndet,
+                                                       const int* __restrict__ n_tab, AnmsParams ap,
+                                                       double2* __restrict__ sel_xy, int* __restrict__ sel_cnt) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  short* sx = reinterpret_cast<short*>(smem);
+  short* sy = sx + ap.kcap;
+  unsigned short* slot = reinterpret_cast<unsigned short*>(sy + ap.kcap);
+  unsigned short* res = slot + ap.kcap;
+  unsigned int* hkey = reinterpret_cast<unsigned int*>(res + ap.kcap);
+  unsigned int* hval = hkey + ap.hash_size;
+  volatile uint8_t* state = reinterpret_cast<volatile uint8_t*>(hval + ap.hash_size);
+  __shared__ int s_low, s_high, s_width, s_prev, s_done, s_nres, s_base;
+  __shared__ unsigned int s_kmin, s_kmax;
+  __shared__ int s_wave[4];
+  const int stream = blockIdx.x;
+  const int n = ndet[stream];
+  int need = ap.max_features - n_tab[stream];  // :174-175
+  need = need > 0 ? need : 0;
+  const short2* K = kp + (long long)stream * ap.kcap;
+  double2* out = sel_xy + (long long)stream * ap.kcap;
+  if (need >= n) {  // :184-186 every detected keypoint, in GFTT order
+    for (int i = threadIdx.x; i < n; i += 256) out[i] = make_double2((double)K[i].x, (double)K[i].y);
+    if (threadIdx.x == 0) sel_cnt[stream] = n;
+    return;
+  }
+  if (need == 0) {  // the reference calls Ssc(numRetPoints = 0): undefined there; nothing is added here
+    if (threadIdx.x == 0) sel_cnt[stream] = 0;
+    return;
+  }
+  // NonMaximumSuppression.cpp:43-53: responses truncate to int 0, cv::sortIdx DESCENDING = reversed std::sort
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const short2 p = K[introsort_equal_src(n, n - 1 - i)];
+    sx[i] = p.x;
+    sy[i] = p.y;
+  }
+  if (threadIdx.x == 0) {
+    const int rows = ap.h, cols = ap.w, num = need;
+    const int exp1 = rows + cols + 2 * num;  // anms.cpp:350-366
+    const long long exp2 = ((long long)4 * cols + (long long)4 * num + (long long)4 * rows * num +
+                            (long long)rows * rows + (long long)cols * cols - (long long)2 * rows * cols +
+                            (long long)4 * rows * cols * num);
+    const double exp3 = sqrt((double)exp2);
+    const double exp4 = num - 1;
+    const double sol1 = -round((exp1 + exp3) / exp4);
+    const double sol2 = -round((exp1 - exp3) / exp4);
+    s_high = (int)((sol1 > sol2) ? sol1 : sol2);
+    s_low = (int)floor(sqrt((double)n / num));
+    s_prev = -1;
+    s_nres = 0;
+    s_done = 0;
+    const float Kf = (float)(unsigned int)num;  // :374-375 unsigned * float
+    s_kmin = (unsigned int)roundf(Kf - (Kf * ap.tolerance));
+    s_kmax = (unsigned int)roundf(Kf + (Kf * ap.tolerance));
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (;;) {
+    if (threadIdx.x == 0) {
+      const int width = s_low + (s_high - s_low) / 2;  // :380
+      if (width == s_prev || s_low > s_high) s_done = 1;  // :381-386: keep the previous result
+      s_width = width;
+    }
+    __syncthreads();
+    if (s_done) break;
+    const int width = s_width;
+    for (int i = threadIdx.x; i < ap.hash_size; i += 256) {
+      hkey[i] = 0xffffffffu;
+      hval[i] = 0xffffffffu;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+      const unsigned int row = (unsigned int)(2 * (int)sy[i]) / (unsigned int)width;
+      const unsigned int col = (unsigned int)(2 * (int)sx[i]) / (unsigned int)width;
+      const unsigned int key = (row << 16) | col;
+      unsigned int h = (key * 2654435761u) >> (32 - ap.hash_bits);
+      for (;;) {
+        const unsigned int old = atomicCAS(&hkey[h], 0xffffffffu, key);
+        if (old == 0xffffffffu || old == key) break;
+        h = (h + 1) & (unsigned int)(ap.hash_size - 1);
+      }
+      slot[i] = (unsigned short)h;
+      atomicMin(&hval[h], (unsigned int)i);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) state[i] = (hval[slot[i]] == (unsigned int)i) ? 0 : 2;  // 0 U, 1 A, 2 R
+    __syncthreads();
+    for (;;) {
+      int undecided = 0;
+      for (int i = threadIdx.x; i < n; i += 256) {
+        if (state[i] != 0) continue;
+        const int row = (2 * (int)sy[i]) / width, col = (2 * (int)sx[i]) / width;
+        bool rejected = false, blocked = false;
+        for (int dr = -2; dr <= 2 && !rejected; dr++)
+          for (int dc = -2; dc <= 2; dc++) {
+            if (dr == 0 && dc == 0) continue;
+            const int rr = row + dr, cc = col + dc;
+            if (rr < 0 || cc < 0) continue;
+            const unsigned int key = ((unsigned int)rr << 16) | (unsigned int)cc;
+            unsigned int h = (key * 2654435761u) >> (32 - ap.hash_bits);
+            unsigned int j = 0xffffffffu;
+            for (;;) {
+              const unsigned int k2 = hkey[h];
+              if (k2 == 0xffffffffu) break;
+              if (k2 == key) {
+                j = hval[h];
+                break;
+              }
+              h = (h + 1) & (unsigned int)(ap.hash_size - 1);
+            }
+            if (j < (unsigned int)i) {
+              const uint8_t st = state[j];
+              if (st == 1) {
+                rejected = true;
+                break;
+              }
+              if (st == 0) blocked = true;
+            }
+          }
+        if (rejected)
+          state[i] = 2;
+        else if (!blocked)
+          state[i] = 1;
+        else
+          undecided = 1;
+      }
+      if (!__syncthreads_or(undecided)) break;
+    }
+    // result = accepted keypoints in sweep order
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 256) {
+      const int i = c0 + threadIdx.x;
+      const bool acc = (i < n) && state[i] == 1;
+      const unsigned long long bal = __ballot(acc);
+      if (lane == 0) s_wave[wv] = __popcll(bal);
+      __syncthreads();
+      int off = s_base;
+      for (int q = 0; q < wv; q++) off += s_wave[q];
+      off += __popcll(bal & ((1ull << lane) - 1ull));
+      if (acc) res[off] = (unsigned short)i;
+      __syncthreads();
+      if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const unsigned int nres = (unsigned int)s_base;
+      s_nres = s_base;
+      if (nres >= s_kmin && nres <= s_kmax)  // :423-430
+        s_done = 1;
+      else if (nres < s_kmin)
+        s_high = width - 1;
+      else
+        s_low = width + 1;
+      s_prev = width;
+    }
+    __syncthreads();
+    if (s_done) break;
+  }
+  const int nres = s_nres;
+  for (int k = threadIdx.x; k < nres; k += 256) out[k] = make_double2((double)sx[res[k]], (double)sy[res[k]]);
+  if (threadIdx.x == 0) sel_cnt[stream] = nres;
+}
+
+}  // namespace vsf

@@ -80,6 +80,19 @@ struct vsf_ctx {
   double2* d_selxy = nullptr;
   int* d_selcnt = nullptr;
   float k_side = 0.f, k_mid = 0.f;
+  // ANMS detector (detector_kind == VSF_DETECTOR_ANMS)
+  AnmsParams anms;
+  float ak_side = 0.f, ak_mid = 0.f;
+  uint8_t* d_aflag = nullptr;             // [B][H][W] the mask GFTT sees
+  int4* d_arect = nullptr;                // the frame as a single cell
+  float2* d_aorigin = nullptr;
+  int* d_alamoff = nullptr;
+  int* d_anact = nullptr;                 // [B] all ones
+  unsigned long long* d_acand = nullptr;  // [B][cand_cap]
+  short2* d_akp = nullptr;                // [B][kcap] detected keypoints, cv order
+  int* d_andet = nullptr;                 // [B]
+  double2* d_aselxy = nullptr;            // [B][kcap]
+  int* d_aselcnt = nullptr;               // [B]
   // LK
   LkParams lk;
   LkSmem lks;
@@ -258,8 +271,12 @@ int track_impl(vsf_ctx* c, const FrameRef& f, int streams, hipStream_t s) {
   return VSF_OK;
 }
 
+int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long mask_sstride, int mask_pitch,
+                     int streams, hipStream_t s);
+
 int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long mask_sstride, int mask_pitch,
                 int streams, hipStream_t s) {
+  if (c->p.detector_kind == VSF_DETECTOR_ANMS) return detect_anms_impl(c, f, masks, mask_sstride, mask_pitch, streams, s);
   const GridView G = grid_view(c);
   const int W = c->p.width, H = c->p.height;
   {
@@ -271,7 +288,7 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
   const int tiles_x = (c->max_cw + SC_TW - 1) / SC_TW, tiles_y = (c->max_ch + SC_TH - 1) / SC_TH;
   {
     ProfScope prof(c, VSF_K_SCORE, s);
-    hipLaunchKernelGGL(score_kernel, dim3(tiles_x * tiles_y, c->ncell, streams), dim3(256), 0, s, f.ptr, f.sstride,
+    hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y, c->ncell, streams), dim3(256), 0, s, f.ptr, f.sstride,
                        f.pitch, W, H, masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, c->k_side, c->k_mid,
                        c->d_lam, c->d_cellmax);
   }
@@ -299,7 +316,65 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
     const int sel_cap = c->grid_max > 0 ? c->grid_max : 1;
     const size_t sm = (size_t)(c->ncell + 1 + c->ncell * sel_cap) * sizeof(int);
     hipLaunchKernelGGL(append_kernel, dim3(streams), dim3(256), sm, s, G, c->d_nact, c->d_selxy, c->d_selcnt,
-                       sel_cap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, c->d_maxidx, c->d_status);
+                       sel_cap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, c->d_maxidx, (uint64_t)0, c->d_status);
+  }
+  HIPCHK(c, hipGetLastError());
+  return VSF_OK;
+}
+
+int anms_ssc_smem(const AnmsParams& a) { return a.kcap * (2 + 2 + 2 + 2 + 1) + a.hash_size * 8 + 16; }
+
+// FeatureDetectorANMS::Detect on `streams` streams (ref: FeatureDetectorANMS.cpp:69-212)
+int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long mask_sstride, int mask_pitch,
+                     int streams, hipStream_t s) {
+  const AnmsParams& ap = c->anms;
+  const int W = ap.w, H = ap.h;
+  GridView G;
+  G.rects = c->d_arect;
+  G.origin = c->d_aorigin;
+  G.lam_off = c->d_alamoff;
+  G.ncell = 1;
+  G.rows = G.cols = 1;
+  G.grid_max = ap.kcap;
+  G.lam_total = c->lam_total;
+  {
+    ProfScope prof(c, VSF_K_OCCUPANCY, s);
+    hipLaunchKernelGGL(anms_mask_kernel, dim3((W + 1023) / 1024, H, streams), dim3(256), 0, s, masks, mask_sstride,
+                       mask_pitch, ap, c->d_aflag);
+    hipLaunchKernelGGL(anms_disc_kernel, dim3(streams), dim3(256), 0, s, c->d_xy, c->d_n, c->cap, ap, c->d_aflag,
+                       c->d_cellmax, c->d_candcnt);
+  }
+  const int tiles_x = (W + SC_TW - 1) / SC_TW, tiles_y = (H + SC_TH - 1) / SC_TH;
+  const long long fsz = (long long)W * H;
+  {
+    ProfScope prof(c, VSF_K_SCORE, s);
+    if (c->p.anms_block_size == 4)
+      hipLaunchKernelGGL(score_kernel<4>, dim3(tiles_x * tiles_y, 1, streams), dim3(256), 0, s, f.ptr, f.sstride,
+                         f.pitch, W, H, c->d_aflag, fsz, W, G, c->d_anact, tiles_x, c->ak_side, c->ak_mid, c->d_lam,
+                         c->d_cellmax);
+    else
+      hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y, 1, streams), dim3(256), 0, s, f.ptr, f.sstride,
+                         f.pitch, W, H, c->d_aflag, fsz, W, G, c->d_anact, tiles_x, c->ak_side, c->ak_mid, c->d_lam,
+                         c->d_cellmax);
+  }
+  {
+    ProfScope prof(c, VSF_K_CANDIDATES, s);
+    hipLaunchKernelGGL(candidate_kernel, dim3(tiles_x * tiles_y, 1, streams), dim3(256), 0, s, c->d_lam, G, c->d_anact,
+                       tiles_x, c->d_cellmax, ap.quality, c->d_aflag, fsz, W, c->d_acand, ap.cand_cap, c->d_candcnt);
+  }
+  {
+    ProfScope prof(c, VSF_K_SELECT, s);
+    hipLaunchKernelGGL(anms_topk_kernel, dim3(streams), dim3(256), (size_t)ap.kcap * 8, s, c->d_lam,
+                       (long long)c->lam_total, c->d_aflag, c->d_cellmax, c->d_acand, c->d_candcnt, ap, c->d_akp,
+                       c->d_andet);
+    hipLaunchKernelGGL(anms_ssc_kernel, dim3(streams), dim3(256), (size_t)anms_ssc_smem(ap), s, c->d_akp, c->d_andet,
+                       c->d_n, ap, c->d_aselxy, c->d_aselcnt);
+  }
+  {
+    ProfScope prof(c, VSF_K_APPEND, s);
+    const size_t sm = (size_t)(2 + ap.kcap) * sizeof(int);
+    hipLaunchKernelGGL(append_kernel, dim3(streams), dim3(256), sm, s, G, c->d_anact, c->d_aselxy, c->d_aselcnt,
+                       ap.kcap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, c->d_maxidx, (uint64_t)1, c->d_status);
   }
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
@@ -408,6 +483,12 @@ void vsf_default_params(vsf_params* p) {
   p->streams = 1;
   p->capacity = 0;
   p->device_id = 0;
+  p->detector_kind = VSF_DETECTOR_BUCKETING;
+  p->anms_detection_features = 0;  // 2 * max_features
+  p->anms_quality_level = 0.001;
+  p->anms_block_size = 4;
+  p->anms_ignore_edge = 20;
+  p->anms_tolerance = 0.1;
 }
 
 const char* vsf_last_error(const vsf_ctx* ctx) { return ctx ? ctx->err : "null context"; }
@@ -427,7 +508,8 @@ void vsf_destroy(vsf_ctx* c) {
   void* bufs[] = {c->det_frame, c->det_mask, c->d_ids,    c->d_xy,      c->d_age,   c->d_n,      c->d_fwd,
                   c->d_flags,   c->d_stats,  c->d_status, c->d_maxidx,  c->d_rects, c->d_origin, c->d_lam_off,
                   c->d_need,    c->d_nact,   c->d_cellmax, c->d_candcnt, c->d_cand,  c->d_lam,    c->d_selxy,
-                  c->d_selcnt};
+                  c->d_selcnt,  c->d_aflag,  c->d_arect,  c->d_aorigin, c->d_alamoff, c->d_anact, c->d_acand,
+                  c->d_akp,     c->d_andet,  c->d_aselxy, c->d_aselcnt};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& e : c->ev_used) {
@@ -450,6 +532,17 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   if (p->width <= p->klt_win || p->height <= p->klt_win) return VSF_E_INVALID;
   if (p->grid_rows < 1 || p->grid_cols < 1 || p->max_features < 0 || p->block_size != 3) return VSF_E_INVALID;
   if (!(p->min_distance >= 0.0) || !(p->quality_level >= 0.0)) return VSF_E_INVALID;
+  const bool use_anms = p->detector_kind == VSF_DETECTOR_ANMS;
+  if (p->detector_kind != VSF_DETECTOR_BUCKETING && !use_anms) return VSF_E_INVALID;
+  int anms_k = 0;
+  if (use_anms) {
+    anms_k = p->anms_detection_features > 0 ? p->anms_detection_features : 2 * p->max_features;
+    if (anms_k < 1 || anms_k > 2048 || (int)p->min_distance > ANMS_MAX_RADIUS || (int)p->min_distance < 0)
+      return VSF_E_INVALID;
+    if (p->anms_block_size != 3 && p->anms_block_size != 4) return VSF_E_INVALID;
+    if (!(p->anms_quality_level >= 0.0) || !(p->anms_tolerance >= 0.0) || p->anms_ignore_edge < 0) return VSF_E_INVALID;
+    if (p->width > 32767 || p->height > 32767) return VSF_E_INVALID;  // keypoints travel as short2
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device_id < 0 || p->device_id >= ndev)
     return VSF_E_HIP;  // no GPU: fail loudly, there is no CPU path
@@ -459,7 +552,8 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   if (!c) return VSF_E_NOMEM;
   c->p = *p;
   c->B = p->streams;
-  c->cap = p->capacity > 0 ? p->capacity : p->max_features + 64;
+  // the ANMS detector may add up to detection_feature_number corners in one call (:184-186)
+  c->cap = p->capacity > 0 ? p->capacity : p->max_features + 64 + (use_anms ? anms_k : 0);
   const int B = c->B;
 
   // pyramid geometry: cv::buildOpticalFlowPyramid stops when the NEXT level would be <= the window
@@ -543,6 +637,45 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     c->k_mid = (float)(2.0 * scale);
   }
 
+  if (use_anms) {
+    AnmsParams& a = c->anms;
+    memset(&a, 0, sizeof(a));
+    a.w = p->width;
+    a.h = p->height;
+    a.max_features = p->max_features;
+    a.radius = (int)p->min_distance;  // FeatureDetectorANMS.cpp:127 static_cast<int>
+    a.edge = p->anms_ignore_edge;
+    a.nfeatures = anms_k;
+    a.tolerance = (float)p->anms_tolerance;  // :181 static_cast<float>
+    a.kcap = 64;
+    while (a.kcap < anms_k) a.kcap <<= 1;
+    a.hash_size = 2 * a.kcap;
+    a.hash_bits = 0;
+    while ((1 << a.hash_bits) < a.hash_size) a.hash_bits++;
+    a.cand_cap = (p->width * p->height) / 8;
+    if (a.cand_cap < 4096) a.cand_cap = 4096;
+    a.quality = p->anms_quality_level;
+    {  // cv::Circle (drawing.cpp), fill: midpoint walk; span on rows +-dy is +-dx and on rows +-dx is +-dy
+      for (int i = 0; i <= ANMS_MAX_RADIUS; i++) a.halfw[i] = -1;
+      int err = 0, dx = a.radius, dy = 0, plus = 1, minus = (a.radius << 1) - 1;
+      while (dx >= dy) {
+        if (dx > a.halfw[dy]) a.halfw[dy] = dx;
+        if (dy > a.halfw[dx]) a.halfw[dx] = dy;
+        dy++;
+        err += plus;
+        plus += 2;
+        const int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+      }
+    }
+    const double scale = 1.0 / ((double)(1 << 2) * p->anms_block_size * 255.0);
+    c->ak_side = (float)(1.0 * scale);
+    c->ak_mid = (float)(2.0 * scale);
+    if (c->lam_total < p->width * p->height) c->lam_total = p->width * p->height;
+  }
+
   int rc = VSF_OK;
 #define A(expr)                 \
   do {                          \
@@ -576,6 +709,18 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   A(dalloc(c, &c->d_lam, (size_t)B * c->lam_total));
   A(dalloc(c, &c->d_selxy, BC * (size_t)(c->grid_max > 0 ? c->grid_max : 1)));
   A(dalloc(c, &c->d_selcnt, BC));
+  if (use_anms) {
+    A(dalloc(c, &c->d_aflag, (size_t)B * fs));
+    A(dalloc(c, &c->d_arect, (size_t)1));
+    A(dalloc(c, &c->d_aorigin, (size_t)1));
+    A(dalloc(c, &c->d_alamoff, (size_t)2));
+    A(dalloc(c, &c->d_anact, (size_t)B));
+    A(dalloc(c, &c->d_acand, (size_t)B * c->anms.cand_cap));
+    A(dalloc(c, &c->d_akp, (size_t)B * c->anms.kcap));
+    A(dalloc(c, &c->d_andet, (size_t)B));
+    A(dalloc(c, &c->d_aselxy, (size_t)B * c->anms.kcap));
+    A(dalloc(c, &c->d_aselcnt, (size_t)B));
+  }
 #undef A
   if (!rc) {
     hipError_t e = hipSuccess;
@@ -603,6 +748,24 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     if (app_sm > 48 * 1024)
       acc(hipFuncSetAttribute(reinterpret_cast<const void*>(append_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, app_sm));
+    if (use_anms) {
+      const int4 r = make_int4(0, 0, p->width, p->height);
+      const float2 o = make_float2(0.f, 0.f);
+      const int lo[2] = {0, p->width * p->height};
+      std::vector<int> ones((size_t)B, 1);
+      acc(hipMemcpy(c->d_arect, &r, sizeof(r), hipMemcpyHostToDevice));
+      acc(hipMemcpy(c->d_aorigin, &o, sizeof(o), hipMemcpyHostToDevice));
+      acc(hipMemcpy(c->d_alamoff, lo, sizeof(lo), hipMemcpyHostToDevice));
+      acc(hipMemcpy(c->d_anact, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice));
+      const int ssc_sm = anms_ssc_smem(c->anms);
+      if (ssc_sm > 48 * 1024)
+        acc(hipFuncSetAttribute(reinterpret_cast<const void*>(anms_ssc_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, ssc_sm));
+      const int aapp_sm = (2 + c->anms.kcap) * 4;
+      if (aapp_sm > app_sm && aapp_sm > 48 * 1024)
+        acc(hipFuncSetAttribute(reinterpret_cast<const void*>(append_kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, aapp_sm));
+    }
     if (e != hipSuccess) rc = VSF_E_HIP;
   }
   if (rc) {
@@ -906,7 +1069,7 @@ int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
   HIPCHK(c, hipMemcpy(c->d_nact, &c->ncell, 4, hipMemcpyHostToDevice));
   const int tiles_x = (c->max_cw + SC_TW - 1) / SC_TW, tiles_y = (c->max_ch + SC_TH - 1) / SC_TH;
   const FrameRef f = own_ref(c, c->det_frame);
-  hipLaunchKernelGGL(score_kernel, dim3(tiles_x * tiles_y, c->ncell, 1), dim3(256), 0, nullptr, f.ptr, f.sstride,
+  hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y, c->ncell, 1), dim3(256), 0, nullptr, f.ptr, f.sstride,
                      f.pitch, w, h, (const uint8_t*)nullptr, 0ll, 0, G, c->d_nact, tiles_x, c->k_side, c->k_mid,
                      c->d_lam, c->d_cellmax);
   HIPCHK(c, hipGetLastError());
@@ -930,6 +1093,21 @@ int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
 // ------------------------------------------------------------------------------------------------
 // profiling
 // ------------------------------------------------------------------------------------------------
+int vsf_debug_anms(vsf_ctx* c, int32_t stream, uint8_t* flag_out, int16_t* kp_out, int32_t* n_kp_out) {
+  if (!c || stream < 0 || stream >= c->B) return VSF_E_INVALID;
+  if (c->p.detector_kind != VSF_DETECTOR_ANMS) return fail(c, VSF_E_INVALID, "not an ANMS context");
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  HIPCHK(c, hipDeviceSynchronize());
+  const size_t fs = (size_t)c->p.width * c->p.height;
+  if (flag_out) HIPCHK(c, hipMemcpy(flag_out, c->d_aflag + (size_t)stream * fs, fs, hipMemcpyDeviceToHost));
+  int nd = 0;
+  HIPCHK(c, hipMemcpy(&nd, c->d_andet + stream, 4, hipMemcpyDeviceToHost));
+  if (kp_out && nd > 0)
+    HIPCHK(c, hipMemcpy(kp_out, c->d_akp + (size_t)stream * c->anms.kcap, (size_t)nd * 4, hipMemcpyDeviceToHost));
+  if (n_kp_out) *n_kp_out = nd;
+  return VSF_OK;
+}
+
 int vsf_profile_enable(vsf_ctx* c, int32_t on) {
   if (!c) return VSF_E_INVALID;
   c->prof = on != 0;

@@ -1042,10 +1042,11 @@ __device__ __forceinline__ float float_order_decode(unsigned int e) {
 // Sobel reads the parent image's real pixels (REFLECT_101 only at the true image border); the box
 // filter reflects at the CELL border and sums in double like cv::boxFilter does for 32F input.
 constexpr int SC_TW = 64, SC_TH = 16;
-constexpr int SC_IW = SC_TW + 4, SC_IH = SC_TH + 4;  // staged 8-bit tile (+2 halo)
-constexpr int SC_CW = SC_TW + 2, SC_CH = SC_TH + 2;  // covariance tile (+1 halo)
-constexpr int SC_IP = 72;
+constexpr int SC_IP = 72;  // LDS pitch of the staged 8-bit tile
 
+// BS = blockSize of the box filter: 3 (offsets -1..+1; cv::goodFeaturesToTrack default, the bucketing
+// detector) or 4 (offsets -2..+1: anchor = blockSize / 2; the ANMS detector's GFTTDetector).
+template <int BS>
 __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
                                                     int row_stride, int w, int h,
                                                     const uint8_t* __restrict__ masks, long long mask_sstride,
@@ -1053,8 +1054,12 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
                                                     const int* __restrict__ n_active, int tiles_x,
                                                     float k_side, float k_mid, float* __restrict__ lam,
                                                     unsigned int* __restrict__ cell_max) {
-  __shared__ uint8_t s_img[SC_IH * SC_IP];
-  __shared__ double s_cov[3][SC_CH * SC_CW];
+  constexpr int HL = BS / 2, HR = BS - 1 - HL;             // covariance halo left/top, right/bottom
+  constexpr int CW = SC_TW + HL + HR, CH = SC_TH + HL + HR;  // covariance tile
+  constexpr int IW = CW + 2, IH = CH + 2;                  // staged 8-bit tile (Sobel reads +-1 more)
+  static_assert(IW <= SC_IP, "tile pitch");
+  __shared__ uint8_t s_img[IH * SC_IP];
+  __shared__ double s_cov[3][CH * CW];
   __shared__ unsigned int s_max;
   const int stream = blockIdx.z, cell = blockIdx.y;
   if (cell >= n_active[stream]) return;
@@ -1065,18 +1070,18 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
   if (cx0 >= cw || cy0 >= ch) return;
   const uint8_t* F = frames + (long long)stream * frame_sstride;
   if (threadIdx.x == 0) s_max = 0u;
-  // staged image tile: parent coords [rc.x + cx0 - 2, +SC_IW) x [rc.y + cy0 - 2, +SC_IH)
-  const int gx0 = rc.x + cx0 - 2, gy0 = rc.y + cy0 - 2;
-  for (int i = threadIdx.x; i < SC_IH * SC_IW; i += 256) {
-    const int y = i / SC_IW, x = i - y * SC_IW;
+  // staged image tile: parent coords [rc.x + cx0 - HL - 1, +IW) x [rc.y + cy0 - HL - 1, +IH)
+  const int gx0 = rc.x + cx0 - HL - 1, gy0 = rc.y + cy0 - HL - 1;
+  for (int i = threadIdx.x; i < IH * IW; i += 256) {
+    const int y = i / IW, x = i - y * IW;
     const int gy = reflect101(gy0 + y, h), gx = reflect101(gx0 + x, w);
     s_img[y * SC_IP + x] = F[(long long)gy * row_stride + gx];
   }
   __syncthreads();
-  // covariance at cell coords [cx0-1, cx0+SC_TW+1) x [cy0-1, cy0+SC_TH+1) that lie inside the cell
-  for (int i = threadIdx.x; i < SC_CH * SC_CW; i += 256) {
-    const int y = i / SC_CW, x = i - y * SC_CW;
-    const int cx = cx0 - 1 + x, cy = cy0 - 1 + y;
+  // covariance at cell coords [cx0-HL, cx0+SC_TW+HR) x [cy0-HL, cy0+SC_TH+HR) that lie inside the cell
+  for (int i = threadIdx.x; i < CH * CW; i += 256) {
+    const int y = i / CW, x = i - y * CW;
+    const int cx = cx0 - HL + x, cy = cy0 - HL + y;
     double vxx = 0, vxy = 0, vyy = 0;
     if (cx >= 0 && cx < cw && cy >= 0 && cy < ch) {
       const uint8_t* c = s_img + (y + 1) * SC_IP + (x + 1);
@@ -1108,16 +1113,19 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
     const int y = i / SC_TW, x = i - y * SC_TW;
     const int cx = cx0 + x, cy = cy0 + y;
     if (cx < cw && cy < ch) {
+      int xi[BS];
+#pragma unroll
+      for (int q = 0; q < BS; q++) xi[q] = reflect101(cx - HL + q, cw) - (cx0 - HL);
       double s[3];
 #pragma unroll
-      for (int j = 0; j < 3; j++) {
-        const int yy = reflect101(cy - 1 + j, ch) - (cy0 - 1);
-        const int xa = reflect101(cx - 1, cw) - (cx0 - 1), xb = cx - (cx0 - 1),
-                  xc = reflect101(cx + 1, cw) - (cx0 - 1);
+      for (int j = 0; j < BS; j++) {
+        const int yy = reflect101(cy - HL + j, ch) - (cy0 - HL);
 #pragma unroll
         for (int q = 0; q < 3; q++) {
-          const double* row = s_cov[q] + yy * SC_CW;
-          const double rs = (row[xa] + row[xb]) + row[xc];
+          const double* row = s_cov[q] + yy * CW;
+          double rs = row[xi[0]];  // row sum left to right, then the column of row sums top to bottom
+#pragma unroll
+          for (int t = 1; t < BS; t++) rs += row[xi[t]];
           s[q] = (j == 0) ? rs : s[q] + rs;
         }
       }
@@ -1346,7 +1354,7 @@ __global__ __launch_bounds__(256) void append_kernel(GridView G, const int* __re
                                                      uint64_t* __restrict__ ids, double2* __restrict__ xy,
                                                      uint32_t* __restrict__ age, int* __restrict__ n, int cap,
                                                      uint64_t* __restrict__ max_feature_index,
-                                                     int* __restrict__ status) {
+                                                     uint64_t id_bias, int* __restrict__ status) {
   extern __shared__ __align__(16) uint8_t smem[];
   int* s_off = reinterpret_cast<int*>(smem);       // [ncell+1] prefix of selected counts
   int* s_slot = s_off + (G.ncell + 1);             // [K] slot of each new feature (-1 = append)
@@ -1364,7 +1372,9 @@ __global__ __launch_bounds__(256) void append_kernel(GridView G, const int* __re
   }
   __syncthreads();
   const int K = s_off[G.ncell];
-  const uint64_t start = max_feature_index[stream];
+  // first id issued: the stored index itself for the bucketing detector (Q6: the previous call's last
+  // id is overwritten), stored index + 1 for the ANMS detector (FeatureDetectorANMS.cpp:198)
+  const uint64_t start = max_feature_index[stream] + id_bias;
   const int n0 = n[stream];
   const long long o = (long long)stream * cap;
   for (int k = threadIdx.x; k < K; k += 256) s_slot[k] = -1;
@@ -1449,3 +1459,4 @@ __global__ __launch_bounds__(256) void export_kernel(const uint64_t* __restrict_
 }
 
 }  // namespace vsf
+#include "vsf_anms.hpp"
