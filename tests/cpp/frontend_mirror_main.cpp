@@ -3,9 +3,13 @@
 // UpdateDetection.  Reads raw 8-bit frames, writes the databases after every frame as text; the
 // pytest wrapper (tests/test_gpu_cpp_mirror.py) compares them with the CPU oracle.
 //   usage: frontend_mirror_main frames.raw W H N out.txt rows cols maxN minDist iter eps win lvl back
+// rows == 0 selects FeatureDetectorANMS (Parameter defaults with max_feature_number_ = maxN,
+// min_feature_distance_ = minDist, detection_feature_number_ = 2 * maxN) instead of the bucketing detector.
 #include <cstdio>
 #include <cstdlib>
+#include <functional>
 #include <map>
+#include <memory>
 #include <vector>
 
 #include "vsf_frontend.hpp"
@@ -21,8 +25,23 @@ int main(int argc, char** argv) {
   if (!f || std::fread(buf.data(), 1, buf.size(), f) != buf.size()) return 3;
   std::fclose(f);
   try {
-    vslam::feature::FeatureDetectorShiTomasiBucketing shi_tomasi_detector(std::atoi(argv[6]), std::atoi(argv[7]),
-                                                                          std::atoi(argv[8]), std::atof(argv[9]));
+    std::unique_ptr<vslam::feature::FeatureDetectorBase> detector_ptr;
+    std::function<uint64_t()> max_index;
+    if (std::atoi(argv[6]) == 0) {
+      vslam::feature::FeatureDetectorANMS::Parameter prm;
+      prm.max_feature_number_ = std::atoi(argv[8]);
+      prm.min_feature_distance_ = std::atof(argv[9]);
+      prm.detection_feature_number_ = prm.max_feature_number_ * 2;
+      auto* d = new vslam::feature::FeatureDetectorANMS(prm);
+      detector_ptr.reset(d);
+      max_index = [d]() { return d->max_feature_index(); };
+    } else {
+      auto* d = new vslam::feature::FeatureDetectorShiTomasiBucketing(std::atoi(argv[6]), std::atoi(argv[7]),
+                                                                      std::atoi(argv[8]), std::atof(argv[9]));
+      detector_ptr.reset(d);
+      max_index = [d]() { return d->max_feature_index(); };
+    }
+    vslam::feature::FeatureDetectorBase& shi_tomasi_detector = *detector_ptr;
     vslam::feature::FeatureTrackerLucasKanade kl_tracker(std::atoi(argv[10]), std::atof(argv[11]), std::atoi(argv[12]),
                                                          std::atoi(argv[13]), std::atof(argv[14]));
     vslam::FeaturePositionDatabase prev_feature_position;
@@ -38,7 +57,7 @@ int main(int argc, char** argv) {
         kl_tracker.Track(prev_feature_position, prev_feature_age, prev, frame);
       }
       std::map<uint64_t, vslam::Vec2_t> sorted(prev_feature_position.begin(), prev_feature_position.end());
-      std::fprintf(out, "frame %d %zu %llu\n", k, sorted.size(), (unsigned long long)shi_tomasi_detector.max_feature_index());
+      std::fprintf(out, "frame %d %zu %llu\n", k, sorted.size(), (unsigned long long)max_index());
       for (const auto& [id, p] : sorted)
         std::fprintf(out, "%llu %.17g %.17g %u\n", (unsigned long long)id, p[0], p[1], prev_feature_age[id]);
     }

@@ -15,12 +15,13 @@ def test_mirror_binary_is_built():
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_matches_oracle(oracle, synth, tmp_path):
+@pytest.mark.parametrize("det_args", [(3, 3, 180, 5.0), (0, 0, 120, 9.0)])
+def test_cpp_mirror_matches_oracle(oracle, synth, tmp_path, det_args):
     w, h, n = 400, 300, 5
     frames, _ = synth.sequence(77, w, h, n)
     raw, out = str(tmp_path / "f.raw"), str(tmp_path / "o.txt")
     frames.tofile(raw)
-    det_args, trk_args = (3, 3, 180, 5.0), (30, 0.01, 21, 3, 1.0)
+    trk_args = (30, 0.01, 21, 3, 1.0)
     subprocess.check_call([EXE, raw, str(w), str(h), str(n), out] + [str(v) for v in det_args + trk_args], timeout=120)
     got, cur = [], None
     for line in open(out):
@@ -30,7 +31,8 @@ def test_cpp_mirror_matches_oracle(oracle, synth, tmp_path):
             got.append(cur)
         else:
             cur["tab"][int(p[0])] = (float(p[1]), float(p[2]), int(p[3]))
-    det, trk, tab = oracle.Detector(*det_args), oracle.Tracker(*trk_args, oracle.ACC_EXACT), oracle.FeatureTable(512)
+    det = oracle.Detector(*det_args) if det_args[0] else oracle.AnmsDetector(det_args[2], det_args[3])
+    trk, tab = oracle.Tracker(*trk_args, oracle.ACC_EXACT), oracle.FeatureTable(1024)
     for k in range(n):
         if k == 0:
             det.update_detection(tab, frames[0])

@@ -177,6 +177,99 @@ class FeatureDetectorShiTomasiBucketing : public FeatureDetectorBase {
   size_t capacity_ = 0;
 };
 
+// Mirror of vslam::feature::FeatureDetectorANMS (ref: src/vslam/feature/FeatureDetectorANMS.hpp,
+// FeatureDetectorANMS.cpp:13-67): same Parameter fields, same UpdateDetection.
+class FeatureDetectorANMS : public FeatureDetectorBase {
+ public:
+  class Parameter {
+   public:
+    Parameter()  // FeatureDetectorANMS.cpp:13-35
+        : max_feature_number_(300),
+          min_feature_distance_(10.0),
+          detection_feature_number_(600),
+          detection_min_feature_distance_(1.0),
+          detection_quality_level_(0.001),
+          detection_block_size_(4),
+          detection_use_harris_corner_(false),
+          detection_k_(0.04),
+          detection_ignore_edge_(20),
+          non_max_suppression_tolerance_(0.1) {}
+    int32_t max_feature_number_;
+    double min_feature_distance_;
+    int32_t detection_feature_number_;
+    double detection_min_feature_distance_;
+    double detection_quality_level_;
+    int32_t detection_block_size_;
+    bool detection_use_harris_corner_;
+    double detection_k_;
+    int32_t detection_ignore_edge_;
+    double non_max_suppression_tolerance_;
+  };
+
+  explicit FeatureDetectorANMS(const Parameter parameter, int device_id = 0)
+      : parameter_(parameter), device_id_(device_id) {
+    if (parameter_.detection_use_harris_corner_ || parameter_.detection_min_feature_distance_ != 1.0)
+      throw std::runtime_error("FeatureDetectorANMS: Harris scoring / detection_min_feature_distance_ != 1 unsupported");
+  }
+
+  void UpdateDetection(FeaturePositionDatabase& feature_position, FeatureAgeDatabase& feature_age,
+                       const ImageView& current_image, const ImageView& mask_image = ImageView()) override {
+    const size_t need = feature_position.size() + (size_t)parameter_.detection_feature_number_ + 64;
+    ensure(current_image.cols, current_image.rows, need);
+    std::vector<uint64_t> ids;
+    std::vector<double> xy;
+    std::vector<uint32_t> ag;
+    detail::flatten(feature_position, feature_age, capacity_, ids, xy, ag);
+    int32_t n = (int32_t)feature_position.size();
+    detail::check(ctx_.get(),
+                  vsf_detect(ctx_.get(), current_image.data, current_image.cols, current_image.rows,
+                             current_image.step, mask_image.empty() ? nullptr : mask_image.data, mask_image.step,
+                             ids.data(), xy.data(), ag.data(), &n, (int32_t)capacity_),
+                  "UpdateDetection");
+    detail::unflatten(ids, xy, ag, n, feature_position, feature_age);
+  }
+
+  database_index_t max_feature_index() {
+    uint64_t v = 0;
+    if (ctx_) detail::check(ctx_.get(), vsf_get_max_feature_index(ctx_.get(), 0, &v), "max_feature_index");
+    return v;
+  }
+
+ private:
+  void ensure(int w, int h, size_t need) {
+    if (ctx_ && w == w_ && h == h_ && need <= capacity_) return;
+    uint64_t keep = 0;
+    if (ctx_) vsf_get_max_feature_index(ctx_.get(), 0, &keep);
+    vsf_params p;
+    vsf_default_params(&p);
+    p.detector_kind = VSF_DETECTOR_ANMS;
+    p.max_features = parameter_.max_feature_number_;
+    p.min_distance = parameter_.min_feature_distance_;
+    p.anms_detection_features = parameter_.detection_feature_number_;
+    p.anms_quality_level = parameter_.detection_quality_level_;
+    p.anms_block_size = parameter_.detection_block_size_;
+    p.anms_ignore_edge = parameter_.detection_ignore_edge_;
+    p.anms_tolerance = parameter_.non_max_suppression_tolerance_;
+    p.width = w;
+    p.height = h;
+    p.device_id = device_id_;
+    p.capacity = (int32_t)(need + need / 2);
+    vsf_ctx* c = nullptr;
+    detail::check(nullptr, vsf_create(&p, &c), "vsf_create(ANMS detector)");
+    ctx_.reset(c);
+    w_ = w;
+    h_ = h;
+    capacity_ = (size_t)p.capacity;
+    detail::check(c, vsf_set_max_feature_index(c, 0, keep), "restore counter");
+  }
+
+  Parameter parameter_;
+  int device_id_;
+  detail::CtxPtr ctx_;
+  int w_ = 0, h_ = 0;
+  size_t capacity_ = 0;
+};
+
 class FeatureTrackerBase {
  public:
   FeatureTrackerBase() = default;
