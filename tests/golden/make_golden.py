@@ -73,6 +73,25 @@ def run_case(w, h, seed, n_frames, det_args, trk_args):
             out["%s_det%d_xy" % (tag, k)] = tab.xy[:n].copy()
             out["%s_det%d_age" % (tag, k)] = tab.age[:n].copy()
             out["%s_det%d_maxidx" % (tag, k)] = np.array([det.max_feature_index], np.uint64)
+    # the same sequence with the ANMS detector (FeatureDetectorANMS) in place of the bucketing one
+    amax, adist = int(det_args[2]), max(float(det_args[3]), 4.0)
+    out["anms_args"] = np.array([amax, adist], np.float64)
+    det = O.AnmsDetector(amax, adist)
+    trk = O.Tracker(*trk_args, O.ACC_EXACT)
+    tab = O.FeatureTable(CAP * 2)
+    for k in range(n_frames):
+        rc, st = trk.track(tab, frames[k])
+        assert rc == 0
+        n = tab.n.value
+        out["anms_mask%d" % k] = np.packbits(det.build_mask(w, h, tab.xy[:n]))
+        assert det.update_detection(tab, frames[k]) in (0, 1)
+        n = tab.n.value
+        out["anms_det%d_ids" % k] = tab.ids[:n].copy()
+        out["anms_det%d_xy" % k] = tab.xy[:n].copy()
+        out["anms_det%d_age" % k] = tab.age[:n].copy()
+        out["anms_det%d_maxidx" % k] = np.array([det.max_feature_index], np.uint64)
+    out["anms_kp0"] = O.good_features_to_track(frames[0], 2 * amax, 0.001, 1.0,
+                                               mask=det.build_mask(w, h, np.zeros((0, 2))), block_size=4)
     return out
 
 

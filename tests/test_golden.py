@@ -55,5 +55,29 @@ def test_oracle_matches_golden(oracle, path):
             assert det.max_feature_index == int(g["%s_det%d_maxidx" % (tag, k)][0])
 
 
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_oracle_anms_matches_golden(oracle, path):
+    g = np.load(path)
+    frames = g["frames"]
+    t = g["trk_args"]
+    trk_args = (int(t[0]), float(t[1]), int(t[2]), int(t[3]), float(t[4]))
+    amax, adist = int(g["anms_args"][0]), float(g["anms_args"][1])
+    h, w = frames[0].shape
+    det, trk, tab = oracle.AnmsDetector(amax, adist), oracle.Tracker(*trk_args, oracle.ACC_EXACT), oracle.FeatureTable(2 * CAP)
+    kp0 = oracle.good_features_to_track(frames[0], 2 * amax, 0.001, 1.0,
+                                        mask=det.build_mask(w, h, np.zeros((0, 2))), block_size=4)
+    assert np.array_equal(kp0, g["anms_kp0"])
+    for k in range(len(frames)):
+        rc, _ = trk.track(tab, frames[k])
+        n = tab.n.value
+        assert rc == 0 and np.array_equal(np.packbits(det.build_mask(w, h, tab.xy[:n])), g["anms_mask%d" % k])
+        assert det.update_detection(tab, frames[k]) in (0, 1)
+        n = tab.n.value
+        assert np.array_equal(tab.ids[:n], g["anms_det%d_ids" % k])
+        assert np.array_equal(tab.xy[:n], g["anms_det%d_xy" % k])
+        assert np.array_equal(tab.age[:n], g["anms_det%d_age" % k])
+        assert det.max_feature_index == int(g["anms_det%d_maxidx" % k][0])
+
+
 def test_golden_fixtures_exist():
     assert len(GOLD) >= 3

@@ -127,3 +127,33 @@ def test_anms_batch_matches_single(vsf, oracle, synth):
             assert np.array_equal(xy[s, :m], tabs[s].xy[:m])
             assert np.array_equal(age[s, :m], tabs[s].age[:m])
     assert (ctx.batch_status() == 0).all()
+
+
+def test_anms_golden_fixtures_on_gpu(vsf):
+    """The committed golden vectors (tests/golden/*.npz, generated from the oracle) through the C ABI."""
+    import glob
+    import os
+    paths = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert paths
+    for path in paths:
+        g = np.load(path)
+        frames = g["frames"]
+        t = g["trk_args"]
+        amax, adist = int(g["anms_args"][0]), float(g["anms_args"][1])
+        h, w = frames[0].shape
+        ctx = vsf.Context(_params(vsf, w, h, amax, adist, klt_max_iter=int(t[0]), klt_eps=float(t[1]),
+                                  klt_win=int(t[2]), klt_max_level=int(t[3]), backtrack_thr=float(t[4])))
+        ids, xy, age = _table(ctx.capacity)
+        n = 0
+        for k in range(len(frames)):
+            n, _ = ctx.track(frames[k], ids, xy, age, n)
+            n = ctx.detect(frames[k], ids, xy, age, n)
+            flag, kp = ctx.debug_anms()
+            assert np.array_equal(np.packbits(flag), g["anms_mask%d" % k])
+            if k == 0:
+                assert np.array_equal(kp.astype(np.float32), g["anms_kp0"])
+            assert np.array_equal(ids[:n], g["anms_det%d_ids" % k])
+            assert np.array_equal(xy[:n], g["anms_det%d_xy" % k])
+            assert np.array_equal(age[:n], g["anms_det%d_age" % k])
+            assert ctx.get_max_feature_index() == int(g["anms_det%d_maxidx" % k][0])
+        ctx.close()

@@ -575,6 +575,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     k.win = p->klt_win;
     k.nseg = 64 / k.win;
     k.seglen = (k.win + k.nseg - 1) / k.nseg;
+    k.nseg_inv = (65536 + k.nseg - 1) / k.nseg;
     int mc = p->klt_max_iter;  // cv: TermCriteria clamp
     mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);
     k.max_count = mc;

@@ -39,6 +39,7 @@ struct LkParams {
   int win;        // window side
   int nseg;       // segments per window row (64 / win)
   int seglen;     // pixels per lane
+  int nseg_inv;   // ceil(2^16 / nseg): (lane * nseg_inv) >> 16 == lane / nseg for lane < 64
   int max_count;  // clamped iteration count
   double eps2;    // clamped eps, squared
   float eps2_lo;  // float s = dx^2 + dy^2 <= eps2_lo  =>  the double test is true
@@ -503,19 +504,12 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
   constexpr int NJ = (SEG <= 8) ? 4 : 10;   // J-region staging tasks per lane (jmargin 3: 28 rows / 8; 38 / 4)
   constexpr int NP = (SEG + 1) / 2;         // pixel pairs per lane
   constexpr int NRAW = (SEG <= 8) ? 3 : 2;  // raw DPP steps of the exact sums (see wave_sums_exact_lds)
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
   const int win = prm.win;
-  const int r = lane / prm.nseg;
-  const int x0 = (lane - r * prm.nseg) * prm.seglen;
-  const bool owner = (r < win) && (x0 < win);                // lane owns at least one window pixel
-  const int rr = owner ? r : 0, xx0 = owner ? x0 : 0;        // idle lanes read a valid (unused) place
   uint8_t* sI = smem;
   uint8_t* sJ = smem + L.off_j;
   int* sD = reinterpret_cast<int*>(smem + L.off_d);
   long long* sAcc = reinterpret_cast<long long*>(smem + L.off_acc);
-  const unsigned int* sMask = reinterpret_cast<const unsigned int*>(smem + L.off_mask) + lane * NP;
-  const int rowI = __mul24(rr, L.gi.pitch);
-  const uint8_t* rowJ0 = sJ + __mul24(rr, L.gj.pitch) + xx0;
   const float half = (float)(win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (float)(1 << 20);
   const int maxLevel = A.nlevels - 1;
@@ -525,6 +519,19 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
   int jx0 = 0, jy0 = 0;
 
   for (int level = maxLevel; level >= 0; level--) {
+    // An opaque zero, new in every level: whatever derives from (lane0 + oz) cannot be hoisted out of
+    // the level loop.  Hoisted, these dozen addresses and masks stay live through the whole kernel and
+    // push the 96-register build into scratch spills; recomputing them costs ~15 instructions a level.
+    int oz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+    const int lane = lane0 + oz;
+    const int r = (lane * prm.nseg_inv) >> 16;  // lane / nseg
+    const int x0 = (lane - r * prm.nseg) * prm.seglen;
+    const bool owner = (r < win) && (x0 < win);                // lane owns at least one window pixel
+    const int rr = owner ? r : 0, xx0 = owner ? x0 : 0;        // idle lanes read a valid (unused) place
+    const unsigned int* sMask = reinterpret_cast<const unsigned int*>(smem + L.off_mask) + lane * NP;
+    const int rowI = __mul24(rr, L.gi.pitch);
+    const uint8_t* rowJ0 = sJ + __mul24(rr, L.gj.pitch) + xx0;
     const float lscale = 1.f / (float)(1 << level);
     float px = ptx * lscale, py = pty * lscale;
     if (level == maxLevel) {
@@ -584,22 +591,35 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         // rows, then applies the separable Scharr stencil; nothing goes through LDS again.
         constexpr int NC = SEG + 2;            // V columns: window columns xx0-1 .. xx0+SEG
         constexpr int NAV = (NC + 1 + 3) / 4;  // aligned dwords holding NC+1 bytes
-        unsigned int R0[NAV], R1[NAV], R2[NAV], R3[NAV];
+        // The three V rows are produced one after the other and folded into the vertical Scharr sums
+        // at once (T0 = 3 V0 + 10 V1 + 3 V2, T1 = V2 - V0), so at most one V row is live.
         const uint8_t* rI = sI + rowI;
-        lds_stream<NAV>(rI, oI + xx0, R0);
-        lds_stream<NAV>(rI + L.gi.pitch, oI + xx0, R1);
-        lds_stream<NAV>(rI + 2 * L.gi.pitch, oI + xx0, R2);
-        lds_stream<NAV>(rI + 3 * L.gi.pitch, oI + xx0, R3);
-        int V0[NC], V1[NC], V2[NC];
         const bool wpos = iw11 >= 0;  // the other three weights are rounded products of non-negatives
-        bilinear_row<NC, NAV, 0>(wpos, R0, R1, W0, W1, V0);
-        bilinear_row<NC, NAV, 0>(wpos, R1, R2, W0, W1, V1);
-        bilinear_row<NC, NAV, 0>(wpos, R2, R3, W0, W1, V2);
         int T0[NC], T1[NC];
+        {
+          unsigned int Ra[NAV], Rb[NAV];
+          int V[NC];
+          lds_stream<NAV>(rI, oI + xx0, Ra);
+          lds_stream<NAV>(rI + L.gi.pitch, oI + xx0, Rb);
+          bilinear_row<NC, NAV, 0>(wpos, Ra, Rb, W0, W1, V);  // V0
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-          T0[c] = __mul24(V0[c] + V2[c], 3) + __mul24(V1[c], 10);  // < 2^27
-          T1[c] = V2[c] - V0[c];
+          for (int c = 0; c < NC; c++) {
+            T0[c] = __mul24(V[c], 3);
+            T1[c] = -V[c];
+          }
+          lds_stream<NAV>(rI + 2 * L.gi.pitch, oI + xx0, Ra);
+          bilinear_row<NC, NAV, 0>(wpos, Rb, Ra, W0, W1, V);  // V1
+#pragma unroll
+          for (int c = 0; c < NC; c++) T0[c] += __mul24(V[c], 10);
+#pragma unroll
+          for (int k = 0; k < SEG; k++) Iw[k] = VSF_DESCALE(V[k + 1], W_BITS - 5);
+          lds_stream<NAV>(rI + 3 * L.gi.pitch, oI + xx0, Rb);
+          bilinear_row<NC, NAV, 0>(wpos, Ra, Rb, W0, W1, V);  // V2
+#pragma unroll
+          for (int c = 0; c < NC; c++) {
+            T0[c] += __mul24(V[c], 3);  // < 2^27
+            T1[c] += V[c];
+          }
         }
         int ixv[SEG + 1], iyv[SEG + 1];
         ixv[SEG] = 0;
@@ -608,7 +628,6 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         for (int k = 0; k < SEG; k++) {
           ixv[k] = VSF_DESCALE(T0[k + 2] - T0[k], W_BITS);
           iyv[k] = VSF_DESCALE(3 * (T1[k] + T1[k + 2]) + 10 * T1[k + 1], W_BITS);
-          Iw[k] = VSF_DESCALE(V1[k + 1], W_BITS - 5);
         }
         // pixels a lane does not own carry zero gradients, so they add nothing to any sum
 #pragma unroll
