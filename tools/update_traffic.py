@@ -26,8 +26,8 @@ out = {
                   "run (byte loads, known traffic): FETCH_SIZE over the 3 levels = 536 MB vs 485 MB source bytes + "
                   "~12 % tile-halo re-reads = 543 MB, i.e. factor 1.0.",
     "note": "XCD-aware block mapping keeps each stream's windows in one L2 (2,911,273 KB fetched per launch before "
-            "it). Writes are dominated by the register-spill scratch of the 96-VGPR build (8 spilled VGPRs), not by "
-            "the 9-byte-per-feature results.",
+            "it). Traffic stays below the algorithmic bytes because only the feature windows of each "
+            "pyramid are touched; writes are the 9-byte-per-feature results (no register-spill scratch).",
 }
 json.dump(out, open(os.path.join(root, "profiles", "lk_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
