@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--streams", type=int, default=1024, help="independent streams (frames per step) per GPU")
     ap.add_argument("--seq", type=int, default=6, help="distinct frames per stream held in HBM")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--detector", choices=("bucketing", "anms"), default="bucketing",
+                    help="FeatureDetectorShiTomasiBucketing (the headline configuration) or FeatureDetectorANMS")
     ap.add_argument("--cpu-streams", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=100)
     args = ap.parse_args()
@@ -128,7 +130,8 @@ def main():
     p = vsf.default_params(grid_rows=GRID[0], grid_cols=GRID[1], max_features=MAX_FEATURES,
                            min_distance=MIN_DIST, klt_win=WIN, klt_max_level=LEVELS - 1, klt_max_iter=30,
                            klt_eps=0.01, backtrack_thr=1.0, width=W, height=H, streams=B,
-                           device_id=local_rank)
+                           device_id=local_rank,
+                           detector_kind=vsf.DETECTOR_ANMS if args.detector == "anms" else vsf.DETECTOR_BUCKETING)
     ctx = vsf.Context(p)
     cap = ctx.capacity
     stream = torch.cuda.current_stream().cuda_stream
@@ -208,7 +211,8 @@ def main():
             "dtype": "u8/i32 (f32 2x2 solve)",
             "data": "synthetic",
             "config": {"workload": "C2: synthetic 752x480 8-bit frames, 4-level pyramid, 21x21 LK window, "
-                                   "4x4 grid / 300 features, %d streams per GPU resident in HBM" % B,
+                                   "%s / 300 features, %d streams per GPU resident in HBM"
+                                   % ("4x4 grid" if args.detector == "bucketing" else "ANMS detector", B),
                        "streams_per_gpu": B, "frames_per_step": world * B,
                        "mean_features_per_stream": mean_feats, "verified_fraction": kept_frac},
             "roofline": {"bound": "hbm", "kernel": "lk_fb_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9,
@@ -217,7 +221,7 @@ def main():
             "step_hbm_frac": alg_step * value / world / HBM_PEAK,
             "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and args.detector == "bucketing":
             line["cpu_baseline"] = cpu_baseline(frames, order, args)
         print(json.dumps(line))
     if dist is not None:

@@ -1,0 +1,111 @@
+"""Edge cases through the C ABI against the oracle: empty tables, texture-free frames, features on
+and beyond the borders, every LK window size the kernels are instantiated for, error returns."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _table(cap):
+    return np.zeros(cap, np.uint64), np.zeros((cap, 2), np.float64), np.zeros(cap, np.uint32)
+
+
+def test_empty_table_and_flat_frames(vsf, oracle):
+    w, h = 200, 150
+    flat = np.full((h, w), 97, np.uint8)
+    for kind in (vsf.DETECTOR_BUCKETING, vsf.DETECTOR_ANMS):
+        ctx = vsf.Context(vsf.default_params(width=w, height=h, max_features=40, grid_rows=2, grid_cols=2,
+                                             min_distance=5.0, detector_kind=kind))
+        ids, xy, age = _table(ctx.capacity)
+        n, stats = ctx.track(flat, ids, xy, age, 0)          # first call: stores the frame
+        assert n == 0
+        n, stats = ctx.track(flat, ids, xy, age, 0)          # empty table: nothing to track
+        assert n == 0 and tuple(stats) == (0, 0, 0, 0)
+        n = ctx.detect(flat, ids, xy, age, 0)                 # no texture: max eigenvalue 0, no corner
+        assert n == 0
+        # every feature lost on a flat frame pair (min-eigenvalue test fails at level 0)
+        ids[:3] = [5, 6, 7]
+        xy[:3] = [[50.5, 60.25], [100.0, 75.0], [150.75, 20.5]]
+        age[:3] = 2
+        n, stats = ctx.track(flat, ids, xy, age, 3)
+        assert n == 0 and stats[0] == 3 and stats[3] == 0
+        ctx.close()
+    # oracle agrees on the bucketing counter quirk for a call that adds nothing (Q6: wraps to 2^64 - 1)
+    ctx = vsf.Context(vsf.default_params(width=w, height=h, max_features=40, grid_rows=2, grid_cols=2))
+    ids, xy, age = _table(ctx.capacity)
+    assert ctx.detect(flat, ids, xy, age, 0) == 0
+    det = oracle.Detector(2, 2, 40, 2.0)
+    T = oracle.FeatureTable(ctx.capacity)
+    det.update_detection(T, flat)
+    assert ctx.get_max_feature_index() == det.max_feature_index == 2 ** 64 - 1
+
+
+@pytest.mark.parametrize("win", [3, 5, 7, 8, 9, 13, 16, 17, 21, 22, 24, 27, 31])
+def test_lk_every_window_size(vsf, oracle, synth, win):
+    w, h = 260, 200
+    frames, _ = synth.sequence(50 + win, w, h, 2)
+    rng = np.random.default_rng(win)
+    n = 257
+    pts = np.stack([rng.uniform(-win, w + win, n), rng.uniform(-win, h + win, n)], 1).astype(np.float32)
+    pts[:16] = [[0, 0], [w - 1, h - 1], [0.5, h - 0.5], [w - 0.5, 0.5], [-win, -win], [w + win - 1, h + win - 1],
+                [win / 2, win / 2], [w - win / 2, h - win / 2], [1e-3, 1e-3], [w / 2, -0.25], [-0.25, h / 2],
+                [w - 1e-3, h / 2], [w / 2, h - 1e-3], [10, 10], [10.5, 10.5], [w - 10.25, h - 10.75]]
+    for ml in (0, 3):
+        ctx = vsf.Context(vsf.default_params(width=w, height=h, klt_win=win, klt_max_level=ml))
+        got, gst = ctx.debug_lk(frames[0], frames[1], pts)
+        ref, rst, _ = oracle.calc_optical_flow_pyr_lk(frames[0], frames[1], pts, win, ml, 30, 0.01,
+                                                      acc_mode=oracle.ACC_EXACT)
+        assert np.array_equal(gst, rst)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        ctx.close()
+
+
+def test_features_outside_and_on_the_border(vsf, oracle, synth):
+    w, h = 320, 240
+    frames, _ = synth.sequence(9, w, h, 2)
+    ctx = vsf.Context(vsf.default_params(width=w, height=h, max_features=64, grid_rows=2, grid_cols=2))
+    cap = ctx.capacity
+    ids, xy, age = _table(cap)
+    pre = np.array([[-30.0, 50.0], [-20.9, -20.9], [0.0, 0.0], [319.999, 239.999], [340.5, 100.0], [100.0, 262.0],
+                    [160.3, 120.7], [5.0, 5.0], [315.0, 236.0], [1e6, 1e6], [-1e6, 30.0]])
+    k = len(pre)
+    ids[:k] = np.arange(10, 10 + k)
+    xy[:k] = pre
+    age[:k] = 3
+    trk = oracle.Tracker(30, 0.01, 21, 3, 1.0, acc_mode=oracle.ACC_EXACT)
+    T = oracle.FeatureTable(cap)
+    T.set(ids[:k].copy(), pre.copy(), age[:k].copy())
+    n, stats = ctx.track_pair(frames[0], frames[1], ids, xy, age, k)
+    rc, rstats = trk.track_pair(T, frames[0], frames[1])
+    assert n == T.n.value and tuple(stats) == tuple(rstats)
+    assert np.array_equal(ids[:n], T.ids[:n]) and np.array_equal(xy[:n], T.xy[:n])
+    # detection with those (partly outside) features present: occupancy and NN rules (Q4, Q5)
+    ids[:k] = np.arange(10, 10 + k)
+    xy[:k] = pre
+    T.set(ids[:k].copy(), pre.copy(), age[:k].copy())
+    det = oracle.Detector(2, 2, 64, 2.0)
+    n = ctx.detect(frames[0], ids, xy, age, k)
+    assert det.update_detection(T, frames[0]) == 0
+    assert n == T.n.value and np.array_equal(ids[:n], T.ids[:n]) and np.array_equal(xy[:n], T.xy[:n])
+
+
+def test_error_returns(vsf, synth):
+    with pytest.raises(vsf.VsfError):
+        vsf.Context(vsf.default_params(width=16, height=16))                       # frame not larger than the window
+    with pytest.raises(vsf.VsfError):
+        vsf.Context(vsf.default_params(klt_win=33))
+    with pytest.raises(vsf.VsfError):
+        vsf.Context(vsf.default_params(detector_kind=7))
+    with pytest.raises(vsf.VsfError):
+        vsf.Context(vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, max_features=2000))  # 4000 > 2048 keypoints
+    with pytest.raises(vsf.VsfError):
+        vsf.Context(vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, min_distance=40.0))  # disc radius > 31
+    ctx = vsf.Context(vsf.default_params(width=200, height=150))
+    ids, xy, age = _table(ctx.capacity)
+    wrong = np.zeros((100, 100), np.uint8)
+    with pytest.raises(vsf.VsfError) as e:
+        ctx.detect(wrong, ids, xy, age, 0)
+    assert e.value.code == -4  # VSF_E_GEOMETRY
+    with pytest.raises(vsf.VsfError) as e:
+        ctx.track(np.zeros((150, 200), np.uint8), ids, xy, age, ctx.capacity + 1)
+    assert e.value.code == -3  # VSF_E_CAPACITY
