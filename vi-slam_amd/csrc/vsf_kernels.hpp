@@ -1061,7 +1061,7 @@ __device__ __forceinline__ float float_order_decode(unsigned int e) {
 // Sobel reads the parent image's real pixels (REFLECT_101 only at the true image border); the box
 // filter reflects at the CELL border and sums in double like cv::boxFilter does for 32F input.
 constexpr int SC_TW = 64, SC_TH = 16;
-constexpr int SC_IP = 72;  // LDS pitch of the staged 8-bit tile
+constexpr int SC_IP = 80;  // LDS pitch of the staged 8-bit tile (tile width + up to 3 bytes of dword alignment)
 
 // BS = blockSize of the box filter: 3 (offsets -1..+1; cv::goodFeaturesToTrack default, the bucketing
 // detector) or 4 (offsets -2..+1: anchor = blockSize / 2; the ANMS detector's GFTTDetector).
@@ -1076,9 +1076,9 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
   constexpr int HL = BS / 2, HR = BS - 1 - HL;             // covariance halo left/top, right/bottom
   constexpr int CW = SC_TW + HL + HR, CH = SC_TH + HL + HR;  // covariance tile
   constexpr int IW = CW + 2, IH = CH + 2;                  // staged 8-bit tile (Sobel reads +-1 more)
-  static_assert(IW <= SC_IP, "tile pitch");
-  __shared__ uint8_t s_img[IH * SC_IP];
-  __shared__ double s_cov[3][CH * CW];
+  static_assert(IW + 3 <= SC_IP && SC_IP % 4 == 0, "tile pitch");
+  __shared__ __align__(16) uint8_t s_img[IH * SC_IP];
+  __shared__ float s_cov[3][CH * CW];  // dx*dx, dx*dy, dy*dy: float32 products, as cv computes them
   __shared__ unsigned int s_max;
   const int stream = blockIdx.z, cell = blockIdx.y;
   if (cell >= n_active[stream]) return;
@@ -1091,19 +1091,35 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
   if (threadIdx.x == 0) s_max = 0u;
   // staged image tile: parent coords [rc.x + cx0 - HL - 1, +IW) x [rc.y + cy0 - HL - 1, +IH)
   const int gx0 = rc.x + cx0 - HL - 1, gy0 = rc.y + cy0 - HL - 1;
-  for (int i = threadIdx.x; i < IH * IW; i += 256) {
-    const int y = i / IW, x = i - y * IW;
-    const int gy = reflect101(gy0 + y, h), gx = reflect101(gx0 + x, w);
-    s_img[y * SC_IP + x] = F[(long long)gy * row_stride + gx];
+  // tiles away from the image border are fetched as aligned dwords (sh = bytes of alignment slack);
+  // border tiles byte by byte with REFLECT_101
+  const int sh = gx0 & 3;
+  constexpr int NDW = (IW + 3 + 3) / 4;
+  const bool img_interior = gx0 >= 0 && gy0 >= 0 && gx0 + IW <= w && gy0 + IH <= h && (row_stride & 3) == 0 &&
+                            (reinterpret_cast<uintptr_t>(F) & 3) == 0 && (gx0 - sh) + 4 * NDW <= row_stride;
+  if (img_interior) {
+    const unsigned int* Fw = reinterpret_cast<const unsigned int*>(F + (long long)gy0 * row_stride + (gx0 - sh));
+    const unsigned int rsw = (unsigned int)row_stride >> 2;
+    unsigned int* sw = reinterpret_cast<unsigned int*>(s_img);
+    for (int i = threadIdx.x; i < IH * NDW; i += 256) {
+      const int y = i / NDW, xd = i - y * NDW;
+      sw[y * (SC_IP / 4) + xd] = Fw[(unsigned int)y * rsw + (unsigned int)xd];
+    }
+  } else {
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+      const int y = i / IW, x = i - y * IW;
+      const int gy = reflect101(gy0 + y, h), gx = reflect101(gx0 + x, w);
+      s_img[y * SC_IP + sh + x] = F[(long long)gy * row_stride + gx];
+    }
   }
   __syncthreads();
   // covariance at cell coords [cx0-HL, cx0+SC_TW+HR) x [cy0-HL, cy0+SC_TH+HR) that lie inside the cell
   for (int i = threadIdx.x; i < CH * CW; i += 256) {
     const int y = i / CW, x = i - y * CW;
     const int cx = cx0 - HL + x, cy = cy0 - HL + y;
-    double vxx = 0, vxy = 0, vyy = 0;
+    float vxx = 0, vxy = 0, vyy = 0;
     if (cx >= 0 && cx < cw && cy >= 0 && cy < ch) {
-      const uint8_t* c = s_img + (y + 1) * SC_IP + (x + 1);
+      const uint8_t* c = s_img + (y + 1) * SC_IP + (sh + x + 1);
       const int p = SC_IP;
       const float r_m = (float)((int)c[-p + 1] - (int)c[-p - 1]);
       const float r_0 = (float)((int)c[1] - (int)c[-1]);
@@ -1116,9 +1132,9 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
       s_p += k_mid * (float)c[p];
       s_p += k_side * (float)c[p + 1];
       const float dy = s_p - s_m;
-      vxx = (double)(dx * dx);
-      vxy = (double)(dx * dy);
-      vyy = (double)(dy * dy);
+      vxx = dx * dx;
+      vxy = dx * dy;
+      vyy = dy * dy;
     }
     s_cov[0][i] = vxx;
     s_cov[1][i] = vxy;
@@ -1128,32 +1144,68 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
   const uint8_t* M = masks ? masks + (long long)stream * mask_sstride : nullptr;
   float* lam_cell = lam + (long long)stream * G.lam_total + G.lam_off[cell];
   unsigned int local_max = 0u;
-  for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
-    const int y = i / SC_TW, x = i - y * SC_TW;
-    const int cx = cx0 + x, cy = cy0 + y;
-    if (cx < cw && cy < ch) {
-      int xi[BS];
+  auto finish = [&](int cx, int cy, const double (&sum)[3]) {
+    const float a = (float)sum[0] * 0.5f, b = (float)sum[1], c = (float)sum[2] * 0.5f;
+    const float lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+    lam_cell[cy * cw + cx] = lm;
+    if (!M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)]) {
+      const unsigned int e = float_order_encode(lm);
+      local_max = max(local_max, e);
+    }
+  };
+  // Box filter in double like cv::boxFilter for 32F input: row sum left to right, then the column of
+  // row sums top to bottom.
+  const bool box_interior = cx0 - HL >= 0 && cx0 + SC_TW + HR <= cw && cy0 - HL >= 0 && cy0 + SC_TH + HR <= ch;
+  if (box_interior) {
+    // no reflection inside the tile: a thread owns one column and four consecutive rows, forms the
+    // BS + 3 row sums they share once, and adds BS of them per pixel (same additions, same order)
+    const int x = threadIdx.x & (SC_TW - 1), y0 = (threadIdx.x / SC_TW) * 4;
+    static_assert(SC_TH == 16 && SC_TW * 4 == 256, "strip mapping");
+    double rs[3][BS + 3];
 #pragma unroll
-      for (int q = 0; q < BS; q++) xi[q] = reflect101(cx - HL + q, cw) - (cx0 - HL);
-      double s[3];
+    for (int k = 0; k < BS + 3; k++) {
 #pragma unroll
-      for (int j = 0; j < BS; j++) {
-        const int yy = reflect101(cy - HL + j, ch) - (cy0 - HL);
+      for (int q = 0; q < 3; q++) {
+        const float* row = s_cov[q] + (y0 + k) * CW + x;
+        double t = (double)row[0];
 #pragma unroll
-        for (int q = 0; q < 3; q++) {
-          const double* row = s_cov[q] + yy * CW;
-          double rs = row[xi[0]];  // row sum left to right, then the column of row sums top to bottom
-#pragma unroll
-          for (int t = 1; t < BS; t++) rs += row[xi[t]];
-          s[q] = (j == 0) ? rs : s[q] + rs;
-        }
+        for (int i = 1; i < BS; i++) t += (double)row[i];
+        rs[q][k] = t;
       }
-      const float a = (float)s[0] * 0.5f, b = (float)s[1], c = (float)s[2] * 0.5f;
-      const float lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-      lam_cell[cy * cw + cx] = lm;
-      if (!M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)]) {
-        const unsigned int e = float_order_encode(lm);
-        local_max = max(local_max, e);
+    }
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      double sum[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        sum[q] = rs[q][o];
+#pragma unroll
+        for (int j = 1; j < BS; j++) sum[q] += rs[q][o + j];
+      }
+      finish(cx0 + x, cy0 + y0 + o, sum);
+    }
+  } else {
+    for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
+      const int y = i / SC_TW, x = i - y * SC_TW;
+      const int cx = cx0 + x, cy = cy0 + y;
+      if (cx < cw && cy < ch) {
+        int xi[BS];
+#pragma unroll
+        for (int q = 0; q < BS; q++) xi[q] = reflect101(cx - HL + q, cw) - (cx0 - HL);
+        double sum[3];
+#pragma unroll
+        for (int j = 0; j < BS; j++) {
+          const int yy = reflect101(cy - HL + j, ch) - (cy0 - HL);
+#pragma unroll
+          for (int q = 0; q < 3; q++) {
+            const float* row = s_cov[q] + yy * CW;
+            double t = (double)row[xi[0]];
+#pragma unroll
+            for (int k = 1; k < BS; k++) t += (double)row[xi[k]];
+            sum[q] = (j == 0) ? t : sum[q] + t;
+          }
+        }
+        finish(cx, cy, sum);
       }
     }
   }
@@ -1185,30 +1237,57 @@ __global__ __launch_bounds__(256) void candidate_kernel(const float* __restrict_
   const float thr = (float)(maxVal * quality);
   const float* L = lam + (long long)stream * G.lam_total + G.lam_off[cell];
   const uint8_t* M = masks ? masks + (long long)stream * mask_sstride : nullptr;
+  // thresholded lambda tile (+1 halo) in LDS; survivors are gathered in LDS too, and ONE global atomic
+  // per block reserves their slots in the cell's list (the order inside the list does not matter)
+  constexpr int LW = SC_TW + 2, LH = SC_TH + 2;
+  constexpr int LCAP = SC_TH * SC_TW / 4 + 64;  // beyond it (plateaus of equal values) keys go straight to the list
+  __shared__ float s_lam[LH * LW];
+  __shared__ unsigned long long s_keys[LCAP];
+  __shared__ int s_n, s_base;
+  if (threadIdx.x == 0) s_n = 0;
+  for (int i = threadIdx.x; i < LH * LW; i += 256) {
+    const int y = i / LW, x = i - y * LW;
+    const int cx = cx0 - 1 + x, cy = cy0 - 1 + y;
+    float v = 0.f;  // outside the cell: never read by an interior pixel's 3x3 test
+    if (cx >= 0 && cx < cw && cy >= 0 && cy < ch) {
+      v = L[cy * cw + cx];
+      v = v > thr ? v : 0.f;  // cv::threshold(THRESH_TOZERO)
+    }
+    s_lam[i] = v;
+  }
+  __syncthreads();
   for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
     const int y = i / SC_TW, x = i - y * SC_TW;
     const int cx = cx0 + x, cy = cy0 + y;
     if (cx >= 1 && cx < cw - 1 && cy >= 1 && cy < ch - 1) {
-      float v = L[cy * cw + cx];
-      v = v > thr ? v : 0.f;
+      const float* c = s_lam + (y + 1) * LW + (x + 1);
+      const float v = c[0];
       if (v != 0.f) {
         float m = v;
 #pragma unroll
         for (int j = -1; j <= 1; j++)
 #pragma unroll
-          for (int q = -1; q <= 1; q++) {
-            float t = L[(cy + j) * cw + (cx + q)];
-            t = t > thr ? t : 0.f;
-            m = fmaxf(m, t);
-          }
+          for (int q = -1; q <= 1; q++) m = fmaxf(m, c[j * LW + q]);
         if (v == m && (!M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)])) {
-          const int slot = atomicAdd(&cand_cnt[stream * G.ncell + cell], 1);
-          if (slot < cand_cap)
-            cand[((long long)stream * G.ncell + cell) * cand_cap + slot] =
-                ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)(cy * cw + cx);
+          const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)(cy * cw + cx);
+          const int ls = atomicAdd(&s_n, 1);
+          if (ls < LCAP) {
+            s_keys[ls] = key;
+          } else {
+            const int slot = atomicAdd(&cand_cnt[stream * G.ncell + cell], 1);
+            if (slot < cand_cap) cand[((long long)stream * G.ncell + cell) * cand_cap + slot] = key;
+          }
         }
       }
     }
+  }
+  __syncthreads();
+  const int nl = min(s_n, LCAP);
+  if (threadIdx.x == 0 && nl > 0) s_base = atomicAdd(&cand_cnt[stream * G.ncell + cell], nl);
+  __syncthreads();
+  for (int i = threadIdx.x; i < nl; i += 256) {
+    const int slot = s_base + i;
+    if (slot < cand_cap) cand[((long long)stream * G.ncell + cell) * cand_cap + slot] = s_keys[i];
   }
 }
 
