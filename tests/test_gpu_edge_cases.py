@@ -109,3 +109,24 @@ def test_error_returns(vsf, synth):
     with pytest.raises(vsf.VsfError) as e:
         ctx.track(np.zeros((150, 200), np.uint8), ids, xy, age, ctx.capacity + 1)
     assert e.value.code == -3  # VSF_E_CAPACITY
+
+
+def test_table_larger_than_the_lk_grid(vsf, oracle, synth):
+    """More table entries than workgroups per stream (max_features + 64): workgroups loop over features."""
+    w, h = 320, 240
+    frames, _ = synth.sequence(31, w, h, 2)
+    ctx = vsf.Context(vsf.default_params(width=w, height=h, max_features=10, capacity=700))
+    cap = ctx.capacity
+    ids, xy, age = _table(cap)
+    rng = np.random.default_rng(1)
+    k = 613
+    ids[:k] = np.arange(1, k + 1)
+    xy[:k] = np.stack([rng.uniform(5, w - 5, k), rng.uniform(5, h - 5, k)], 1)
+    age[:k] = 1
+    trk = oracle.Tracker(30, 0.01, 21, 3, 1.0, acc_mode=oracle.ACC_EXACT)
+    T = oracle.FeatureTable(cap)
+    T.set(ids[:k].copy(), xy[:k].copy(), age[:k].copy())
+    n, stats = ctx.track_pair(frames[0], frames[1], ids, xy, age, k)
+    rc, rstats = trk.track_pair(T, frames[0], frames[1])
+    assert n == T.n.value and tuple(stats) == tuple(rstats)
+    assert np.array_equal(ids[:n], T.ids[:n]) and np.array_equal(xy[:n], T.xy[:n])

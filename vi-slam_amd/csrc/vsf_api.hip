@@ -217,10 +217,13 @@ int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hi
     HIPCHK(c, hipGetLastError());
     return VSF_OK;
   }
-  dim3 grid((unsigned)(8 * c->cap * ((streams + 7) / 8)));  // 8 XCD residue classes x streams x features
-#define VSF_LAUNCH_W(SEG)                                                                                         \
-  hipLaunchKernelGGL(lk_fb_kernel<SEG>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, streams, \
-                     c->lk, c->d_fwd, c->d_flags)
+  // workgroups per stream: the table size a detector maintains (+ slack), not the (larger) capacity
+  int fgrid = c->p.max_features + 64;
+  if (fgrid > c->cap) fgrid = c->cap;
+  dim3 grid((unsigned)(8 * fgrid * ((streams + 7) / 8)));  // 8 XCD residue classes x streams x features
+#define VSF_LAUNCH_W(SEG)                                                                                       \
+  hipLaunchKernelGGL(lk_fb_kernel<SEG>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, fgrid, \
+                     streams, c->lk, c->d_fwd, c->d_flags)
   switch (lk_seg_template(c->lk.seglen)) {
     case 7: VSF_LAUNCH_W(7); break;
     case 8: VSF_LAUNCH_W(8); break;

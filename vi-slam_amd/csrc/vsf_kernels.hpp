@@ -864,35 +864,41 @@ __device__ __forceinline__ void lk_init_masks(const LkParams& prm, uint8_t* smem
 // ||back - original||_2 <= threshold in double against the ORIGINAL double position).
 template <int SEG>
 __global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
-                                                   const int* __restrict__ n, int cap, int nstreams,
+                                                   const int* __restrict__ n, int cap, int fgrid, int nstreams,
                                                    LkParams prm, float2* __restrict__ fwd,
                                                    uint8_t* __restrict__ flags) {
   extern __shared__ __align__(16) uint8_t smem[];
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so all
   // features of one stream are given to ONE residue class: their overlapping window lines are then
   // fetched into a single L2 instead of eight.  Placement is a speed matter only.
+  // fgrid workgroups serve a stream; feature f0 + k * fgrid goes to workgroup f0 (k > 0 only when a
+  // table holds more than fgrid entries, which the usual table size never does).
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int grp = local / cap;
-  const int stream = grp * 8 + xcd, f = local - grp * cap;
-  if (stream >= nstreams || f >= n[stream]) return;
+  const int grp = local / fgrid;
+  const int stream = grp * 8 + xcd, f0 = local - grp * fgrid;
+  if (stream >= nstreams) return;
+  const int nf = n[stream];
+  if (f0 >= nf) return;
   const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
   lk_init_masks<SEG>(prm, smem, L);
-  const double2 p0 = xy[(long long)stream * cap + f];
-  const float p0x = (float)p0.x, p0y = (float)p0.y;  // :210 double -> float narrowing
-  float qx, qy;
-  uint8_t flag = 0;
-  if (lk_track_point<SEG>(P, C, stream, p0x, p0y, qx, qy, prm, smem, L)) {
-    flag |= 1;
-    float rx, ry;
-    if (lk_track_point<SEG>(C, P, stream, qx, qy, rx, ry, prm, smem, L)) {
-      flag |= 2;
-      const double ddx = (double)rx - p0.x, ddy = (double)ry - p0.y;
-      if (sqrt(ddx * ddx + ddy * ddy) <= prm.backtrack_thr) flag |= 4;
+  for (int f = f0; f < nf; f += fgrid) {
+    const double2 p0 = xy[(long long)stream * cap + f];
+    const float p0x = (float)p0.x, p0y = (float)p0.y;  // :210 double -> float narrowing
+    float qx, qy;
+    uint8_t flag = 0;
+    if (lk_track_point<SEG>(P, C, stream, p0x, p0y, qx, qy, prm, smem, L)) {
+      flag |= 1;
+      float rx, ry;
+      if (lk_track_point<SEG>(C, P, stream, qx, qy, rx, ry, prm, smem, L)) {
+        flag |= 2;
+        const double ddx = (double)rx - p0.x, ddy = (double)ry - p0.y;
+        if (sqrt(ddx * ddx + ddy * ddy) <= prm.backtrack_thr) flag |= 4;
+      }
     }
-  }
-  if ((threadIdx.x & 63) == 0) {
-    fwd[(long long)stream * cap + f] = make_float2(qx, qy);
-    flags[(long long)stream * cap + f] = flag;
+    if ((threadIdx.x & 63) == 0) {
+      fwd[(long long)stream * cap + f] = make_float2(qx, qy);
+      flags[(long long)stream * cap + f] = flag;
+    }
   }
 }
 
