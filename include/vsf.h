@@ -165,6 +165,32 @@ int vsf_debug_lk(vsf_ctx* ctx, const uint8_t* prev, const uint8_t* next, int32_t
 int vsf_debug_min_eig(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
                       int32_t cell, float* out, int32_t* rect);
 
+/* ---- frontend step around the path (KimeraFrontend::ProcessFrame, src/vslam/frontend/KimeraFrontend.cpp:247-304) ---- */
+typedef struct vsf_camera_ds {
+  double fx, fy, cx, cy, xi, alpha; /* DoubleSphereCameraModel ctor (src/vslam/data/Camera.cpp:101-122) */
+} vsf_camera_ds;
+typedef struct vsf_keyframe_params {
+  double keyframe_interval;             /* KimeraFrontendParameter.cpp:11  5.0 */
+  double minimum_keyframe_interval;     /* :12  0.5 */
+  uint32_t low_keyframe_feature_number; /* :13  200 */
+  int32_t counting_feature_age;         /* :14  2 */
+} vsf_keyframe_params;
+/* What ProcessFrame does with the tracker's output before RemoveOutlier, for every stream of the
+ * context: bearings = camera_model->Unproject(pos), {0,0,1} where Unproject throws (:247-257); count of
+ * features with age >= counting_feature_age (:266-269); keyframe decision from that count and
+ * dt_since_keyframe[s] = timestamp - last_keyframe->timestamp (:272-293); for a keyframe every age of
+ * the stream is incremented (:302-304).  d_bearings: device buffer of streams*capacity*3 doubles (same
+ * indexing as the tables); dt_since_keyframe, is_keyframe_out, aged_out: host arrays of `streams`
+ * entries (the last two may be NULL).  Synchronises the stream before returning. */
+int vsf_batch_frontend_post_track(vsf_ctx* ctx, const vsf_camera_ds* cam, const vsf_keyframe_params* kp,
+                                  const double* dt_since_keyframe, double* d_bearings, int32_t* is_keyframe_out,
+                                  uint32_t* aged_out, void* hip_stream);
+/* DoubleSphereCameraModel::Unproject on n host points (src/vslam/data/Camera.cpp:181-189): bearings
+ * receives 3n doubles, valid n bytes (0 where the reference throws ProjectionErrorException; the
+ * bearing is then {0,0,1} as at KimeraFrontend.cpp:255). */
+int vsf_unproject(vsf_ctx* ctx, const vsf_camera_ds* cam, const double* xy, int32_t n, double* bearings,
+                  uint8_t* valid);
+
 /* Intermediates of the last vsf_detect / vsf_batch_detect of an ANMS context, for one stream: the mask
  * cv::GFTTDetector saw (FeatureDetectorANMS.cpp:107-132; [h][w] bytes, may be NULL) and the detected
  * keypoints in cv order as x, y int16 pairs (kp may be NULL; at most anms_detection_features pairs). */

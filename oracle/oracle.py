@@ -284,6 +284,43 @@ class AnmsDetector:
                                               w, mptr, mstride, *table._ptrs(), table.capacity)
 
 
+class CameraDS(C.Structure):
+    """DoubleSphereCameraModel intrinsics (ref: src/vslam/data/Camera.hpp:134)."""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("xi", C.c_double), ("alpha", C.c_double)]
+
+
+def ds_unproject(cam, xy):
+    xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+    out = np.zeros((len(xy), 3))
+    ok = np.zeros(len(xy), bool)
+    L = lib()
+    L.orc_ds_unproject.restype = C.c_int
+    for i, (u, v) in enumerate(xy):
+        b = (C.c_double * 3)()
+        ok[i] = bool(L.orc_ds_unproject(C.byref(cam), C.c_double(u), C.c_double(v), b))
+        out[i] = list(b)
+    return out, ok
+
+
+def frontend_post_track(cam, xy, age, counting_feature_age, low_keyframe_feature_number,
+                        minimum_keyframe_interval, keyframe_interval, dt_since_keyframe):
+    """Returns (keyframe, bearings [n][3], aged count); `age` (uint32 array) is incremented in place
+    for a keyframe."""
+    xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+    assert age.dtype == np.uint32 and age.flags["C_CONTIGUOUS"]
+    n = len(xy)
+    bearings = np.zeros((n, 3))
+    aged = C.c_uint32(0)
+    kf = lib().orc_frontend_post_track(C.byref(cam), xy.ctypes.data_as(C.c_void_p),
+                                       age.ctypes.data_as(C.c_void_p), n, int(counting_feature_age),
+                                       C.c_uint32(low_keyframe_feature_number),
+                                       C.c_double(minimum_keyframe_interval), C.c_double(keyframe_interval),
+                                       C.c_double(dt_since_keyframe), bearings.ctypes.data_as(C.c_void_p),
+                                       C.byref(aged))
+    return bool(kf), bearings, aged.value
+
+
 class Tracker:
     """FeatureTrackerLucasKanade (ref: FeatureTrackerLucasKanade.cpp:8-240)."""
 

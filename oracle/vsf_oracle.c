@@ -1032,6 +1032,53 @@ int orc_anms_detector_update(orc_anms_detector* d, const uint8_t* img, int w, in
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* frontend step: bearings, aged count, keyframe decision                                      */
+/* ------------------------------------------------------------------------------------------ */
+int orc_ds_unproject(const orc_camera_ds* cam, double u, double v, double* out3) {
+  const double mx = (u - cam->cx) / cam->fx;
+  const double my = (v - cam->cy) / cam->fy;
+  const double r2 = mx * mx + my * my;
+  if (cam->alpha > 0.5 && r2 >= 1.0 / (2.0 * cam->alpha - 1.0)) return 0;
+  const double xi2_2 = cam->alpha * cam->alpha;
+  const double xi1_2 = cam->xi * cam->xi;
+  const double sqrt2 = sqrt(1.0 - (2.0 * cam->alpha - 1.0) * r2);
+  const double norm2 = cam->alpha * sqrt2 + 1.0 - cam->alpha;
+  const double mz = (1.0 - xi2_2 * r2) / norm2;
+  const double mz2 = mz * mz;
+  const double norm1 = mz2 + r2;
+  const double sqrt1 = sqrt(mz2 + (1.0 - xi1_2) * r2);
+  const double k = (mz * cam->xi + sqrt1) / norm1;
+  out3[0] = k * mx;
+  out3[1] = k * my;
+  out3[2] = k * mz - cam->xi;
+  return 1;
+}
+
+int orc_frontend_post_track(const orc_camera_ds* cam, const double* xy, uint32_t* age, int n,
+                            int32_t counting_feature_age, uint32_t low_keyframe_feature_number,
+                            double minimum_keyframe_interval, double keyframe_interval,
+                            double dt_since_keyframe, double* bearings, uint32_t* aged_out) {
+  for (int i = 0; i < n; i++) { /* :247-257 */
+    double* b = bearings + 3 * i;
+    if (!orc_ds_unproject(cam, xy[2 * i], xy[2 * i + 1], b)) {
+      b[0] = 0;
+      b[1] = 0;
+      b[2] = 1;
+    }
+  }
+  uint32_t aged = 0; /* :266-269: uint32 age against int32 parameter -> unsigned comparison */
+  for (int i = 0; i < n; i++)
+    if (age[i] >= (uint32_t)counting_feature_age) aged++;
+  int low = aged < low_keyframe_feature_number;                 /* :275-276 */
+  if (dt_since_keyframe < minimum_keyframe_interval) low = 0;   /* :278-281 */
+  const int keyframe = low || (dt_since_keyframe > keyframe_interval); /* :291-293 */
+  if (keyframe)
+    for (int i = 0; i < n; i++) age[i]++; /* :302-304 */
+  if (aged_out) *aged_out = aged;
+  return keyframe;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* reference wrapper: FeatureTrackerLucasKanade                                                */
 /* ------------------------------------------------------------------------------------------ */
 /* ref: src/vslam/feature/FeatureTrackerLucasKanade.cpp:8-23 */

@@ -154,6 +154,24 @@ int orc_anms_detector_update(orc_anms_detector* d, const uint8_t* img, int w, in
                              const uint8_t* mask, int mask_stride, uint64_t* ids, double* xy,
                              uint32_t* age, int* n_inout, int capacity);
 
+/* ---- frontend step around the path (ref: src/vslam/frontend/KimeraFrontend.cpp:247-304) ---- */
+typedef struct {
+  double fx, fy, cx, cy, xi, alpha; /* DoubleSphereCameraModel (src/vslam/data/Camera.hpp:134) */
+} orc_camera_ds;
+/* basalt::DoubleSphereCamera<double>::unproject (basalt-headers, absent submodule: restated from
+ * Usenko et al., "The Double Sphere Camera Model", 3DV 2018, eq. 47-50, in basalt's operation
+ * order).  Returns 0 when the pixel is outside the model's domain; out is then left untouched. */
+int orc_ds_unproject(const orc_camera_ds* cam, double u, double v, double* out3);
+/* KimeraFrontend::ProcessFrame between Track and RemoveOutlier: bearings of every tracked feature
+ * ({0,0,1} when Unproject throws, :249-256), the number of features of age >= counting_feature_age
+ * (:266-269), the keyframe decision (:272-293) and, for a keyframe, the age increment (:302-304).
+ * Returns 1 for a keyframe, 0 otherwise. */
+int orc_frontend_post_track(const orc_camera_ds* cam, const double* xy, uint32_t* age, int n,
+                            int32_t counting_feature_age, uint32_t low_keyframe_feature_number,
+                            double minimum_keyframe_interval, double keyframe_interval,
+                            double dt_since_keyframe, double* bearings /* 3n */,
+                            uint32_t* aged_out);
+
 /* One frontend step on `streams` independent streams, used as the timed CPU baseline:
  * track (3-arg) then detect on the same frame.  Parallel over streams with OpenMP when built
  * with -fopenmp (threads = omp default), serial otherwise. */

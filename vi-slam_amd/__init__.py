@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "vsf_batch_upload", "vsf_batch_download", "vsf_batch_device_tables", "vsf_batch_status",
     "vsf_batch_export_tracks",
     "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig", "vsf_debug_anms",
+    "vsf_batch_frontend_post_track", "vsf_unproject",
     "vsf_profile_enable", "vsf_profile_read",
 ]
 
@@ -47,6 +48,24 @@ class VsfParams(C.Structure):
 
 DETECTOR_BUCKETING = 0
 DETECTOR_ANMS = 1
+
+
+class VsfCameraDS(C.Structure):
+    """DoubleSphereCameraModel intrinsics (ref: src/vslam/data/Camera.cpp:101-122)."""
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("xi", C.c_double), ("alpha", C.c_double)]
+
+
+class VsfKeyframeParams(C.Structure):
+    """KimeraFrontend::Parameter fields used by the keyframe decision (KimeraFrontendParameter.cpp:11-14)."""
+    _fields_ = [("keyframe_interval", C.c_double), ("minimum_keyframe_interval", C.c_double),
+                ("low_keyframe_feature_number", C.c_uint32), ("counting_feature_age", C.c_int32)]
+
+
+def keyframe_params(keyframe_interval=5.0, minimum_keyframe_interval=0.5, low_keyframe_feature_number=200,
+                    counting_feature_age=2):
+    return VsfKeyframeParams(keyframe_interval, minimum_keyframe_interval, low_keyframe_feature_number,
+                             counting_feature_age)
 
 
 class VsfTrackStats(C.Structure):
@@ -258,6 +277,27 @@ class Context:
         self._chk(lib().vsf_debug_min_eig(self._h, _vp(img), w, h, w, cell, _vp(out), rect))
         rx, ry, rw, rh = [int(v) for v in rect]
         return out[:rw * rh].reshape(rh, rw).copy(), (rx, ry, rw, rh)
+
+    # ---- frontend step around the path ----
+    def frontend_post_track(self, cam, kp, dt_since_keyframe, d_bearings, stream=0):
+        """KimeraFrontend.cpp:247-304 on every stream: bearings into the device buffer `d_bearings`
+        (streams*capacity*3 doubles), returns (is_keyframe [B], aged [B]); ages of keyframe streams
+        are incremented on the device."""
+        dt = np.ascontiguousarray(dt_since_keyframe, np.float64)
+        assert dt.shape == (self.streams,)
+        kf = np.zeros(self.streams, np.int32)
+        aged = np.zeros(self.streams, np.uint32)
+        self._chk(lib().vsf_batch_frontend_post_track(self._h, C.byref(cam), C.byref(kp), _vp(dt),
+                                                      C.c_void_p(d_bearings), _vp(kf), _vp(aged),
+                                                      C.c_void_p(stream)))
+        return kf, aged
+
+    def unproject(self, cam, xy):
+        xy = np.ascontiguousarray(xy, np.float64).reshape(-1, 2)
+        out = np.zeros((len(xy), 3), np.float64)
+        ok = np.zeros(len(xy), np.uint8)
+        self._chk(lib().vsf_unproject(self._h, C.byref(cam), _vp(xy), len(xy), _vp(out), _vp(ok)))
+        return out, ok.astype(bool)
 
     def debug_anms(self, stream=0):
         """(mask GFTT saw [h][w], detected keypoints [n][2] in cv order) of the last ANMS detection."""

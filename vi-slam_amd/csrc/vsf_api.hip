@@ -93,6 +93,10 @@ struct vsf_ctx {
   int* d_andet = nullptr;                 // [B]
   double2* d_aselxy = nullptr;            // [B][kcap]
   int* d_aselcnt = nullptr;               // [B]
+  // frontend step (allocated on first use)
+  double* d_fe_dt = nullptr;
+  int* d_fe_kf = nullptr;
+  unsigned int* d_fe_aged = nullptr;
   // LK
   LkParams lk;
   LkSmem lks;
@@ -512,7 +516,7 @@ void vsf_destroy(vsf_ctx* c) {
                   c->d_flags,   c->d_stats,  c->d_status, c->d_maxidx,  c->d_rects, c->d_origin, c->d_lam_off,
                   c->d_need,    c->d_nact,   c->d_cellmax, c->d_candcnt, c->d_cand,  c->d_lam,    c->d_selxy,
                   c->d_selcnt,  c->d_aflag,  c->d_arect,  c->d_aorigin, c->d_alamoff, c->d_anact, c->d_acand,
-                  c->d_akp,     c->d_andet,  c->d_aselxy, c->d_aselcnt};
+                  c->d_akp,     c->d_andet,  c->d_aselxy, c->d_aselcnt, c->d_fe_dt,  c->d_fe_kf,  c->d_fe_aged};
   for (void* b : bufs)
     if (b) (void)hipFree(b);
   for (auto& e : c->ev_used) {
@@ -1097,6 +1101,58 @@ int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
 // ------------------------------------------------------------------------------------------------
 // profiling
 // ------------------------------------------------------------------------------------------------
+int vsf_batch_frontend_post_track(vsf_ctx* c, const vsf_camera_ds* cam, const vsf_keyframe_params* kp,
+                                  const double* dt_since_keyframe, double* d_bearings, int32_t* is_keyframe_out,
+                                  uint32_t* aged_out, void* hip_stream) {
+  if (!c || !cam || !kp || !dt_since_keyframe || !d_bearings) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  const int B = c->B;
+  if (!c->d_fe_dt) {
+    int rc = dalloc(c, &c->d_fe_dt, (size_t)B);
+    if (!rc) rc = dalloc(c, &c->d_fe_kf, (size_t)B);
+    if (!rc) rc = dalloc(c, &c->d_fe_aged, (size_t)B);
+    if (rc) return rc;
+  }
+  HIPCHK(c, hipMemcpyAsync(c->d_fe_dt, dt_since_keyframe, (size_t)B * 8, hipMemcpyHostToDevice, s));
+  CameraDS cd = {cam->fx, cam->fy, cam->cx, cam->cy, cam->xi, cam->alpha};
+  KeyframeParams k = {kp->keyframe_interval, kp->minimum_keyframe_interval, kp->low_keyframe_feature_number,
+                      kp->counting_feature_age};
+  hipLaunchKernelGGL(frontend_kernel, dim3(B), dim3(256), 0, s, c->d_xy, c->d_age, c->d_n, c->cap, cd, k, c->d_fe_dt,
+                     d_bearings, c->d_fe_kf, c->d_fe_aged);
+  HIPCHK(c, hipGetLastError());
+  if (is_keyframe_out) HIPCHK(c, hipMemcpyAsync(is_keyframe_out, c->d_fe_kf, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  if (aged_out) HIPCHK(c, hipMemcpyAsync(aged_out, c->d_fe_aged, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(c, hipStreamSynchronize(s));
+  return VSF_OK;
+}
+
+int vsf_unproject(vsf_ctx* c, const vsf_camera_ds* cam, const double* xy, int32_t n, double* bearings,
+                  uint8_t* valid) {
+  if (!c || !cam || n < 0 || (n > 0 && (!xy || !bearings))) return VSF_E_INVALID;
+  if (n == 0) return VSF_OK;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  double *d_in = nullptr, *d_out = nullptr;
+  uint8_t* d_ok = nullptr;
+  int rc = dalloc(c, &d_in, (size_t)n * 2);
+  if (!rc) rc = dalloc(c, &d_out, (size_t)n * 3);
+  if (!rc) rc = dalloc(c, &d_ok, (size_t)n);
+  if (!rc && hipMemcpy(d_in, xy, (size_t)n * 16, hipMemcpyHostToDevice) != hipSuccess) rc = VSF_E_HIP;
+  if (!rc) {
+    CameraDS cd = {cam->fx, cam->fy, cam->cx, cam->cy, cam->xi, cam->alpha};
+    hipLaunchKernelGGL(unproject_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr,
+                       reinterpret_cast<const double2*>(d_in), n, cd, d_out, d_ok);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) rc = VSF_E_HIP;
+  }
+  if (!rc && hipMemcpy(bearings, d_out, (size_t)n * 24, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
+  if (!rc && valid && hipMemcpy(valid, d_ok, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (d_ok) (void)hipFree(d_ok);
+  if (rc == VSF_E_HIP) return fail(c, rc, "vsf_unproject: HIP failure");
+  return rc;
+}
+
 int vsf_debug_anms(vsf_ctx* c, int32_t stream, uint8_t* flag_out, int16_t* kp_out, int32_t* n_kp_out) {
   if (!c || stream < 0 || stream >= c->B) return VSF_E_INVALID;
   if (c->p.detector_kind != VSF_DETECTOR_ANMS) return fail(c, VSF_E_INVALID, "not an ANMS context");

@@ -1529,6 +1529,102 @@ __global__ __launch_bounds__(256) void append_kernel(GridView G, const int* __re
   }
 }
 
+// Frontend step around the path (ref: src/vslam/frontend/KimeraFrontend.cpp:247-304), per stream:
+// bearings of every tracked feature through the double-sphere model ({0,0,1} where the reference's
+// Unproject throws), number of features of age >= counting_feature_age, keyframe decision, and the
+// age increment of a keyframe.  All in double, in the operation order of the CPU code.
+struct CameraDS {
+  double fx, fy, cx, cy, xi, alpha;  // DoubleSphereCameraModel (src/vslam/data/Camera.hpp:134)
+};
+struct KeyframeParams {                  // KimeraFrontend::Parameter (KimeraFrontendParameter.cpp:11-14)
+  double keyframe_interval;
+  double minimum_keyframe_interval;
+  unsigned int low_keyframe_feature_number;
+  int counting_feature_age;
+};
+
+// basalt::DoubleSphereCamera<double>::unproject (Usenko et al., 3DV 2018, eq. 47-50)
+__device__ __forceinline__ bool ds_unproject(const CameraDS& cam, double u, double v, double (&out)[3]) {
+  const double mx = (u - cam.cx) / cam.fx;
+  const double my = (v - cam.cy) / cam.fy;
+  const double r2 = mx * mx + my * my;
+  if (cam.alpha > 0.5 && r2 >= 1.0 / (2.0 * cam.alpha - 1.0)) return false;
+  const double xi2_2 = cam.alpha * cam.alpha;
+  const double xi1_2 = cam.xi * cam.xi;
+  const double sqrt2 = sqrt(1.0 - (2.0 * cam.alpha - 1.0) * r2);
+  const double norm2 = cam.alpha * sqrt2 + 1.0 - cam.alpha;
+  const double mz = (1.0 - xi2_2 * r2) / norm2;
+  const double mz2 = mz * mz;
+  const double norm1 = mz2 + r2;
+  const double sqrt1 = sqrt(mz2 + (1.0 - xi1_2) * r2);
+  const double k = (mz * cam.xi + sqrt1) / norm1;
+  out[0] = k * mx;
+  out[1] = k * my;
+  out[2] = k * mz - cam.xi;
+  return true;
+}
+
+__global__ __launch_bounds__(256) void frontend_kernel(const double2* __restrict__ xy, uint32_t* __restrict__ age,
+                                                       const int* __restrict__ n, int cap, CameraDS cam,
+                                                       KeyframeParams kp, const double* __restrict__ dt_since_keyframe,
+                                                       double* __restrict__ bearings, int* __restrict__ is_keyframe,
+                                                       unsigned int* __restrict__ aged_out) {
+  __shared__ unsigned int s_aged;
+  __shared__ int s_kf;
+  const int stream = blockIdx.x;
+  const int n0 = n[stream];
+  const long long o = (long long)stream * cap;
+  if (threadIdx.x == 0) s_aged = 0u;
+  __syncthreads();
+  unsigned int aged = 0u;
+  for (int i = threadIdx.x; i < n0; i += 256) {
+    const double2 p = xy[o + i];
+    double b[3];
+    if (!ds_unproject(cam, p.x, p.y, b)) {  // :252-256
+      b[0] = 0.0;
+      b[1] = 0.0;
+      b[2] = 1.0;
+    }
+    double* out = bearings + (o + i) * 3;
+    out[0] = b[0];
+    out[1] = b[1];
+    out[2] = b[2];
+    aged += age[o + i] >= (unsigned int)kp.counting_feature_age;  // :268 unsigned comparison
+  }
+  for (int m = 32; m >= 1; m >>= 1) aged += (unsigned int)__shfl_xor((int)aged, m, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&s_aged, aged);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double dt = dt_since_keyframe[stream];
+    bool low = s_aged < kp.low_keyframe_feature_number;  // :275-276
+    if (dt < kp.minimum_keyframe_interval) low = false;  // :278-281
+    s_kf = (low || dt > kp.keyframe_interval) ? 1 : 0;   // :291-293
+    is_keyframe[stream] = s_kf;
+    aged_out[stream] = s_aged;
+  }
+  __syncthreads();
+  if (s_kf)
+    for (int i = threadIdx.x; i < n0; i += 256) age[o + i] += 1u;  // :302-304
+}
+
+__global__ __launch_bounds__(256) void unproject_kernel(const double2* __restrict__ xy, int n, CameraDS cam,
+                                                        double* __restrict__ bearings, uint8_t* __restrict__ valid) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double2 p = xy[i];
+  double b[3];
+  const bool ok = ds_unproject(cam, p.x, p.y, b);
+  if (!ok) {
+    b[0] = 0.0;
+    b[1] = 0.0;
+    b[2] = 1.0;
+  }
+  bearings[3 * i] = b[0];
+  bearings[3 * i + 1] = b[1];
+  bearings[3 * i + 2] = b[2];
+  valid[i] = ok ? 1 : 0;
+}
+
 // Fixed-size track records for the end-of-step collective over xGMI: 24 bytes,
 // padded to the table capacity so every rank contributes the same byte count.
 struct TrackRecord {
