@@ -72,7 +72,18 @@ typedef struct vsf_params {
   int32_t anms_block_size;         /* detection_block_size_ 4 (:26); 3 or 4 */
   int32_t anms_ignore_edge;        /* detection_ignore_edge_ 20 (:29) */
   double anms_tolerance;           /* non_max_suppression_tolerance_ 0.1 (:34) */
+  /* Which FeatureTrackerBase implementation vsf_track / vsf_batch_track / vsf_batch_step run:
+   * VSF_TRACKER_LK = FeatureTrackerLucasKanade (klt_* above), VSF_TRACKER_LSSD =
+   * FeatureTrackerLSSDLucasKanade (FeatureTrackerLSSDLucasKanade.cpp:13-119; basalt frame-to-frame SE(2)
+   * patch tracker, Pattern24, float): fields below are its Parameter (:17-22). */
+  int32_t tracker_kind;
+  int32_t lssd_levels;             /* optical_flow_levels_ 3 (images 0..levels); <= 7 */
+  int32_t lssd_max_iterations;     /* optical_flow_max_iterations_ 5 */
+  double lssd_max_recovered_dist;  /* optical_flow_max_recovered_dist_ 0.09, compared with the SQUARED distance */
 } vsf_params;
+
+#define VSF_TRACKER_LK 0
+#define VSF_TRACKER_LSSD 1
 
 #define VSF_DETECTOR_BUCKETING 0
 #define VSF_DETECTOR_ANMS 1
@@ -190,6 +201,15 @@ int vsf_batch_frontend_post_track(vsf_ctx* ctx, const vsf_camera_ds* cam, const 
  * bearing is then {0,0,1} as at KimeraFrontend.cpp:255). */
 int vsf_unproject(vsf_ctx* ctx, const vsf_camera_ds* cam, const double* xy, int32_t n, double* bearings,
                   uint8_t* valid);
+
+/* FrameToFrameOpticalFlow::TrackPoint (forward only, frame_to_frame_optical_flow_single_thread.cpp:84-112)
+ * on n points of a frame pair, with the context's lssd_* parameters: next_pts 2n floats, valid n bytes. */
+int vsf_debug_lssd(vsf_ctx* ctx, const uint8_t* prev, const uint8_t* next, int32_t w, int32_t h,
+                   const float* prev_pts, float* next_pts, uint8_t* valid, int32_t n);
+/* Level `level` (1..lssd_levels) of the u16 mip pyramid (basalt ManagedImagePyr::setFromImage of the frame
+ * shifted left by 8): out receives (w >> level) * (h >> level) uint16. */
+int vsf_debug_lssd_pyramid(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t level,
+                           uint16_t* out);
 
 /* Intermediates of the last vsf_detect / vsf_batch_detect of an ANMS context, for one stream: the mask
  * cv::GFTTDetector saw (FeatureDetectorANMS.cpp:107-132; [h][w] bytes, may be NULL) and the detected

@@ -284,6 +284,74 @@ class AnmsDetector:
                                               w, mptr, mstride, *table._ptrs(), table.capacity)
 
 
+LSSD_SEQ = 0   # sums in pattern index order, libm sin/cos ("restated reference")
+LSSD_TREE = 1  # 32-slot butterfly sums + polynomial sin/cos (what a half-wavefront reproduces)
+
+
+class _Level16(C.Structure):
+    _fields_ = [("w", C.c_int), ("h", C.c_int), ("data", C.POINTER(C.c_uint16))]
+
+
+class _Pyramid16(C.Structure):
+    _fields_ = [("levels", C.c_int), ("lv", _Level16 * 16)]
+
+
+class _LssdTracker(C.Structure):
+    _fields_ = [("max_recovered_dist", C.c_double), ("max_iterations", C.c_int32), ("levels", C.c_int32),
+                ("mode", C.c_int), ("old_pyr", _Pyramid16), ("has_old", C.c_int)]
+
+
+def lssd_build_pyramid(img, levels=3):
+    """u8 -> u16 (<< 8) -> basalt ManagedImagePyr::setFromImage: list of levels+1 uint16 images."""
+    img = _img(img)
+    h, w = img.shape
+    P = _Pyramid16()
+    rc = lib().orc_lssd_build_pyramid(img.ctypes.data_as(C.c_void_p), w, h, w, levels, C.byref(P))
+    assert rc == 0
+    out = [np.ctypeslib.as_array(P.lv[i].data, shape=(P.lv[i].h, P.lv[i].w)).copy() for i in range(levels + 1)]
+    lib().orc_lssd_free_pyramid(C.byref(P))
+    return out
+
+
+def lssd_track_points(prev, cur, pts, levels=3, max_iterations=5, mode=LSSD_SEQ):
+    """FrameToFrameOpticalFlow::TrackPoint (forward only) on a point list: (next [n][2] f32, valid [n])."""
+    prev, cur = _img(prev), _img(cur)
+    h, w = prev.shape
+    P0, P1 = _Pyramid16(), _Pyramid16()
+    L = lib()
+    L.orc_lssd_build_pyramid(prev.ctypes.data_as(C.c_void_p), w, h, w, levels, C.byref(P0))
+    L.orc_lssd_build_pyramid(cur.ctypes.data_as(C.c_void_p), w, h, w, levels, C.byref(P1))
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+    out = pts.copy()
+    valid = np.zeros(len(pts), np.uint8)
+    for i in range(len(pts)):
+        valid[i] = L.orc_lssd_track_point(C.byref(P0), C.byref(P1), pts[i].ctypes.data_as(C.c_void_p),
+                                          out[i].ctypes.data_as(C.c_void_p), levels, max_iterations, mode)
+    L.orc_lssd_free_pyramid(C.byref(P0))
+    L.orc_lssd_free_pyramid(C.byref(P1))
+    return out, valid
+
+
+class LssdTracker:
+    """FeatureTrackerLSSDLucasKanade (ref: FeatureTrackerLSSDLucasKanade.cpp:13-119)."""
+
+    def __init__(self, max_recovered_dist=0.09, levels=3, max_iterations=5, mode=LSSD_SEQ):
+        self.s = _LssdTracker()
+        lib().orc_lssd_tracker_init(C.byref(self.s), C.c_double(max_recovered_dist), levels, max_iterations, mode)
+
+    def __del__(self):
+        try:
+            lib().orc_lssd_tracker_free(C.byref(self.s))
+        except Exception:
+            pass
+
+    def track(self, table, cur):
+        cur = _img(cur)
+        h, w = cur.shape
+        return lib().orc_lssd_tracker_track(C.byref(self.s), cur.ctypes.data_as(C.c_void_p), w, h, w,
+                                            *table._ptrs())
+
+
 class CameraDS(C.Structure):
     """DoubleSphereCameraModel intrinsics (ref: src/vslam/data/Camera.hpp:134)."""
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),

@@ -607,6 +607,10 @@ int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int s
     const double px = xy[2 * i], py = xy[2 * i + 1];
     if (px > 0 && px < w && py > 0 && py < h) flag[(size_t)((int)py) * w + (int)px] = 1;
   }
+  /* :121-130 the kd-tree is built ONCE from the positions at entry: a feature whose slot the
+   * first new id overwrites (:142 starts at max_feature_index, not +1) keeps its old position in it */
+  double* kd_points = (double*)malloc(sizeof(double) * 2 * (size_t)(n0 > 0 ? n0 : 1));
+  memcpy(kd_points, xy, sizeof(double) * 2 * (size_t)n0);
 
   int rc = 0;
   uint64_t feature_index = d->max_feature_index; /* :142 */
@@ -635,7 +639,7 @@ int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int s
       if (n0 > 0) {
         double best = 0;
         for (int i = 0; i < n0; i++) {
-          const double ddx = cx - xy[2 * i], ddy = cy - xy[2 * i + 1];
+          const double ddx = cx - kd_points[2 * i], ddy = cy - kd_points[2 * i + 1];
           const double d2 = ddx * ddx + ddy * ddy;
           if (i == 0 || d2 < best) best = d2;
         }
@@ -667,6 +671,7 @@ int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int s
   d->max_feature_index = feature_index - 1; /* :238 */
   *n_inout = n;
   free(pts);
+  free(kd_points);
   free(flag);
   free(origin);
   free(rects);
@@ -1032,6 +1037,422 @@ int orc_anms_detector_update(orc_anms_detector* d, const uint8_t* img, int w, in
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* LSSD SE(2) patch tracker (FeatureTrackerLSSDLucasKanade, basalt frame-to-frame optical flow) */
+/* ------------------------------------------------------------------------------------------ */
+/* ref: LSSDOpticalFlow/patterns.h:60-73 (Pattern24::pattern_raw); frame_to_frame_optical_flow_single_thread.hpp:25 */
+static const float LSSD_PATTERN[ORC_LSSD_PATTERN][2] = {
+    {-1, 5},  {1, 5},  {-3, 3},  {-1, 3},  {1, 3},   {3, 3},  {-5, 1},  {-3, 1},
+    {-1, 1},  {1, 1},  {3, 1},   {5, 1},   {-5, -1}, {-3, -1}, {-1, -1}, {1, -1},
+    {3, -1},  {5, -1}, {-3, -3}, {-1, -3}, {1, -3},  {3, -3}, {-1, -5}, {1, -5}};
+
+/* basalt::ManagedImagePyr<uint16_t>::subsample: vertical then horizontal [1 4 6 4 1] in int, borders
+ * abs() / border101(), (v + 128) >> 8 once; size (w/2, h/2) */
+static void lssd_subsample(const orc_level16* s, orc_level16* d) {
+  d->w = s->w / 2;
+  d->h = s->h / 2;
+  d->data = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)(d->w > 0 ? d->w : 1) * (d->h > 0 ? d->h : 1));
+  static const int k[5] = {1, 4, 6, 4, 1};
+  for (int y = 0; y < d->h; y++)
+    for (int x = 0; x < d->w; x++) {
+      int acc = 0;
+      for (int j = -2; j <= 2; j++) {
+        const int yy = reflect101(2 * y + j, s->h);
+        int r = 0;
+        for (int i = -2; i <= 2; i++) r += k[i + 2] * (int)s->data[(size_t)yy * s->w + reflect101(2 * x + i, s->w)];
+        acc += k[j + 2] * r;
+      }
+      d->data[(size_t)y * d->w + x] = (uint16_t)((acc + (1 << 7)) >> 8);
+    }
+}
+
+int orc_lssd_build_pyramid(const uint8_t* img, int w, int h, int stride, int levels, orc_pyramid16* out) {
+  if (levels < 0 || levels >= ORC_MAX_LEVELS) return -1;
+  memset(out, 0, sizeof(*out));
+  out->levels = levels;
+  out->lv[0].w = w;
+  out->lv[0].h = h;
+  out->lv[0].data = (uint16_t*)malloc(sizeof(uint16_t) * (size_t)w * h);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) out->lv[0].data[(size_t)y * w + x] = (uint16_t)((int)img[(size_t)y * stride + x] << 8);
+  for (int l = 0; l < levels; l++) lssd_subsample(&out->lv[l], &out->lv[l + 1]);
+  return 0;
+}
+
+void orc_lssd_free_pyramid(orc_pyramid16* p) {
+  for (int l = 0; l < ORC_MAX_LEVELS; l++) {
+    free(p->lv[l].data);
+    p->lv[l].data = NULL;
+  }
+}
+
+/* basalt::Image::InBounds(p, border) for floating point p */
+static inline int lssd_in_bounds(const orc_level16* im, float x, float y, float border) {
+  return border <= x && x < ((float)im->w - border - 1.f) && border <= y && y < ((float)im->h - border - 1.f);
+}
+static inline float lssd_px(const orc_level16* im, int x, int y) { return (float)im->data[(size_t)y * im->w + x]; }
+/* basalt::Image::interp<float> */
+static inline float lssd_interp(const orc_level16* im, float x, float y) {
+  const int ix = (int)x, iy = (int)y;
+  const float dx = x - (float)ix, dy = y - (float)iy;
+  const float ddx = 1.f - dx, ddy = 1.f - dy;
+  return ddx * ddy * lssd_px(im, ix, iy) + ddx * dy * lssd_px(im, ix, iy + 1) + dx * ddy * lssd_px(im, ix + 1, iy) +
+         dx * dy * lssd_px(im, ix + 1, iy + 1);
+}
+/* basalt::Image::interpGrad<float>: value and central differences of the interpolated image */
+static inline void lssd_interp_grad(const orc_level16* im, float x, float y, float* out3) {
+  const int ix = (int)x, iy = (int)y;
+  const float dx = x - (float)ix, dy = y - (float)iy;
+  const float ddx = 1.f - dx, ddy = 1.f - dy;
+  const float px0y0 = lssd_px(im, ix, iy), px1y0 = lssd_px(im, ix + 1, iy);
+  const float px0y1 = lssd_px(im, ix, iy + 1), px1y1 = lssd_px(im, ix + 1, iy + 1);
+  out3[0] = ddx * ddy * px0y0 + ddx * dy * px0y1 + dx * ddy * px1y0 + dx * dy * px1y1;
+  const float pxm1y0 = lssd_px(im, ix - 1, iy), pxm1y1 = lssd_px(im, ix - 1, iy + 1);
+  const float res_mx = ddx * ddy * pxm1y0 + ddx * dy * pxm1y1 + dx * ddy * px0y0 + dx * dy * px0y1;
+  const float px2y0 = lssd_px(im, ix + 2, iy), px2y1 = lssd_px(im, ix + 2, iy + 1);
+  const float res_px = ddx * ddy * px1y0 + ddx * dy * px1y1 + dx * ddy * px2y0 + dx * dy * px2y1;
+  out3[1] = 0.5f * (res_px - res_mx);
+  const float px0ym1 = lssd_px(im, ix, iy - 1), px1ym1 = lssd_px(im, ix + 1, iy - 1);
+  const float res_my = ddx * ddy * px0ym1 + ddx * dy * px0y0 + dx * ddy * px1ym1 + dx * dy * px1y0;
+  const float px0y2 = lssd_px(im, ix, iy + 2), px1y2 = lssd_px(im, ix + 1, iy + 2);
+  const float res_py = ddx * ddy * px0y1 + ddx * dy * px0y2 + dx * ddy * px1y1 + dx * dy * px1y2;
+  out3[2] = 0.5f * (res_py - res_my);
+}
+
+/* sum of v[0..23] in the selected order */
+static float lssd_sum(const float* v, int mode) {
+  if (mode == ORC_LSSD_SEQ) {
+    float s = 0.f;
+    for (int i = 0; i < ORC_LSSD_PATTERN; i++) s += v[i];
+    return s;
+  }
+  float a[32], b[32];
+  for (int i = 0; i < 32; i++) a[i] = i < ORC_LSSD_PATTERN ? v[i] : 0.f;
+  for (int step = 1; step < 32; step <<= 1) {
+    for (int i = 0; i < 32; i++) b[i] = a[i] + a[i ^ step];
+    memcpy(a, b, sizeof(a));
+  }
+  return a[0];
+}
+
+/* sin / cos for the TREE mode: Taylor polynomials in float (|theta| is far below 1 in this use);
+ * the SEQ mode calls libm like Sophus does */
+static void lssd_sincos(float t, int mode, float* s, float* c) {
+  if (mode == ORC_LSSD_SEQ) {
+    *s = sinf(t);
+    *c = cosf(t);
+    return;
+  }
+  const float t2 = t * t;
+  *s = t * (1.f + t2 * (-1.f / 6.f + t2 * (1.f / 120.f + t2 * (-1.f / 5040.f + t2 * (1.f / 362880.f)))));
+  *c = 1.f + t2 * (-0.5f + t2 * (1.f / 24.f + t2 * (-1.f / 720.f + t2 * (1.f / 40320.f + t2 * (-1.f / 3628800.f)))));
+}
+
+/* Eigen::LDLT<Matrix3f>::compute + solveInPlace(Identity): lower-triangular, diagonal pivoting
+ * (Eigen/src/Cholesky/LDLT.h, ldlt_inplace<Lower>::unblocked, restated for n = 3) */
+static void lssd_ldlt_inverse3(const float H[3][3], float Hinv[3][3]) {
+  float m[3][3];
+  int tr[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) m[i][j] = H[i][j];
+  for (int k = 0; k < 3; k++) {
+    int big = k;
+    float bv = fabsf(m[k][k]);
+    for (int i = k + 1; i < 3; i++)
+      if (fabsf(m[i][i]) > bv) {
+        bv = fabsf(m[i][i]);
+        big = i;
+      }
+    tr[k] = big;
+    if (big != k) { /* symmetric swap of rows/columns k and big, lower triangle only */
+      const int s = 3 - big - 1;
+      for (int j = 0; j < k; j++) {
+        const float t = m[k][j];
+        m[k][j] = m[big][j];
+        m[big][j] = t;
+      }
+      for (int i = 0; i < s; i++) {
+        const float t = m[big + 1 + i][k];
+        m[big + 1 + i][k] = m[big + 1 + i][big];
+        m[big + 1 + i][big] = t;
+      }
+      {
+        const float t = m[k][k];
+        m[k][k] = m[big][big];
+        m[big][big] = t;
+      }
+      for (int i = k + 1; i < big; i++) {
+        const float t = m[i][k];
+        m[i][k] = m[big][i];
+        m[big][i] = t;
+      }
+    }
+    const int rs = 3 - k - 1;
+    if (k > 0) {
+      float temp[3] = {0.f, 0.f, 0.f};
+      for (int j = 0; j < k; j++) temp[j] = m[j][j] * m[k][j];
+      float dot = 0.f;
+      for (int j = 0; j < k; j++) dot = (j == 0) ? m[k][j] * temp[j] : dot + m[k][j] * temp[j];
+      m[k][k] -= dot;
+      for (int i = 0; i < rs; i++) {
+        float d2 = 0.f;
+        for (int j = 0; j < k; j++) d2 = (j == 0) ? m[k + 1 + i][j] * temp[j] : d2 + m[k + 1 + i][j] * temp[j];
+        m[k + 1 + i][k] -= d2;
+      }
+    }
+    const float akk = m[k][k];
+    if (rs > 0 && fabsf(akk) > 0.f)
+      for (int i = 0; i < rs; i++) m[k + 1 + i][k] /= akk;
+  }
+  /* solve for the identity: dst = P b; L^-1; D^-1 (pseudo-inverse with Eigen's tolerance); L^-T; P^T */
+  float X[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) X[i][j] = (i == j) ? 1.f : 0.f;
+  for (int k = 0; k < 3; k++)
+    if (tr[k] != k)
+      for (int j = 0; j < 3; j++) {
+        const float t = X[k][j];
+        X[k][j] = X[tr[k]][j];
+        X[tr[k]][j] = t;
+      }
+  for (int c = 0; c < 3; c++) { /* unit lower triangular forward substitution */
+    for (int i = 1; i < 3; i++)
+      for (int j = 0; j < i; j++) X[i][c] -= m[i][j] * X[j][c];
+  }
+  const float tol = 1.f / 3.4028234663852886e+38f; /* RealScalar(1) / NumTraits<RealScalar>::highest() */
+  for (int i = 0; i < 3; i++)
+    for (int c = 0; c < 3; c++) {
+      if (fabsf(m[i][i]) > tol)
+        X[i][c] /= m[i][i];
+      else
+        X[i][c] = 0.f;
+    }
+  for (int c = 0; c < 3; c++) { /* unit upper triangular (L^T) back substitution */
+    for (int i = 1; i >= 0; i--)
+      for (int j = i + 1; j < 3; j++) X[i][c] -= m[j][i] * X[j][c];
+  }
+  for (int k = 2; k >= 0; k--)
+    if (tr[k] != k)
+      for (int j = 0; j < 3; j++) {
+        const float t = X[k][j];
+        X[k][j] = X[tr[k]][j];
+        X[tr[k]][j] = t;
+      }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Hinv[i][j] = X[i][j];
+}
+
+typedef struct {
+  float data[ORC_LSSD_PATTERN]; /* negative if the point is not valid */
+  float HinvJT[3][ORC_LSSD_PATTERN];
+} lssd_patch;
+
+/* ref: patch.h:75-131 OpticalFlowPatch::setFromImage */
+static void lssd_patch_set(lssd_patch* p, const orc_level16* img, float posx, float posy, int mode) {
+  float val[ORC_LSSD_PATTERN], gx[ORC_LSSD_PATTERN], gy[ORC_LSSD_PATTERN];
+  int num_valid = 0;
+  for (int i = 0; i < ORC_LSSD_PATTERN; i++) {
+    const float x = posx + LSSD_PATTERN[i][0], y = posy + LSSD_PATTERN[i][1];
+    if (lssd_in_bounds(img, x, y, 2.f)) {
+      float vg[3];
+      lssd_interp_grad(img, x, y, vg);
+      p->data[i] = vg[0];
+      val[i] = vg[0];
+      gx[i] = vg[1];
+      gy[i] = vg[2];
+      num_valid++;
+    } else {
+      p->data[i] = -1.f;
+      val[i] = 0.f;
+      gx[i] = 0.f;
+      gy[i] = 0.f;
+    }
+  }
+  const float sum = lssd_sum(val, mode), gsx = lssd_sum(gx, mode), gsy = lssd_sum(gy, mode);
+  const float mean_inv = (float)num_valid / sum; /* :100 */
+  float J[ORC_LSSD_PATTERN][3];
+  for (int i = 0; i < ORC_LSSD_PATTERN; i++) {
+    float jx = 0.f, jy = 0.f;
+    if (p->data[i] >= 0.f) {
+      const float d = p->data[i];
+      /* :111-112 num_valid_points * (grad_i * sum - grad_sum * data_i) / (sum * sum) */
+      jx = ((float)num_valid * (gx[i] * sum - gsx * d)) / (sum * sum);
+      jy = ((float)num_valid * (gy[i] * sum - gsy * d)) / (sum * sum);
+      p->data[i] = d * mean_inv;
+    }
+    /* :120-122 J_se2.row(i) = grad.row(i) * Jw_se2, Jw = [I | (-py, px)^T] */
+    J[i][0] = jx;
+    J[i][1] = jy;
+    J[i][2] = jx * (-LSSD_PATTERN[i][1]) + jy * LSSD_PATTERN[i][0];
+  }
+  float H[3][3], Hinv[3][3], prod[ORC_LSSD_PATTERN];
+  for (int a = 0; a < 3; a++)
+    for (int b = a; b < 3; b++) {
+      for (int i = 0; i < ORC_LSSD_PATTERN; i++) prod[i] = J[i][a] * J[i][b];
+      H[a][b] = H[b][a] = lssd_sum(prod, mode);
+    }
+  lssd_ldlt_inverse3(H, Hinv); /* :125-128 */
+  for (int a = 0; a < 3; a++)  /* :130 */
+    for (int i = 0; i < ORC_LSSD_PATTERN; i++)
+      p->HinvJT[a][i] = (Hinv[a][0] * J[i][0] + Hinv[a][1] * J[i][1]) + Hinv[a][2] * J[i][2];
+}
+
+/* ref: patch.h:133-164 OpticalFlowPatch::residual */
+static int lssd_patch_residual(const lssd_patch* p, const orc_level16* img, const float tp[ORC_LSSD_PATTERN][2],
+                               float* res, int mode) {
+  float val[ORC_LSSD_PATTERN];
+  int num_valid = 0;
+  for (int i = 0; i < ORC_LSSD_PATTERN; i++) {
+    if (lssd_in_bounds(img, tp[i][0], tp[i][1], 2.f)) {
+      res[i] = lssd_interp(img, tp[i][0], tp[i][1]);
+      val[i] = res[i];
+      num_valid++;
+    } else {
+      res[i] = -1.f;
+      val[i] = 0.f;
+    }
+  }
+  const float sum = lssd_sum(val, mode);
+  int num_res = 0;
+  for (int i = 0; i < ORC_LSSD_PATTERN; i++) {
+    if (res[i] >= 0.f && p->data[i] >= 0.f) {
+      res[i] = ((float)num_valid * res[i]) / sum - p->data[i];
+      num_res++;
+    } else {
+      res[i] = 0.f;
+    }
+  }
+  return num_res > ORC_LSSD_PATTERN / 2;
+}
+
+/* ref: frame_to_frame_optical_flow_single_thread.cpp:114-146 TrackPointAtLevel.
+ * T = [L | t] (AffineCompact2f): L row-major 2x2, t */
+static int lssd_track_at_level(const orc_level16* img2, const lssd_patch* dp, float L[2][2], float t[2],
+                               int max_iterations, int mode) {
+  int patch_valid = 1;
+  for (int it = 0; patch_valid && it < max_iterations; it++) {
+    float tp[ORC_LSSD_PATTERN][2], res[ORC_LSSD_PATTERN];
+    for (int i = 0; i < ORC_LSSD_PATTERN; i++) { /* :126-128 */
+      tp[i][0] = (L[0][0] * LSSD_PATTERN[i][0] + L[0][1] * LSSD_PATTERN[i][1]) + t[0];
+      tp[i][1] = (L[1][0] * LSSD_PATTERN[i][0] + L[1][1] * LSSD_PATTERN[i][1]) + t[1];
+    }
+    if (lssd_patch_residual(dp, img2, tp, res, mode)) {
+      float inc[3], prod[ORC_LSSD_PATTERN];
+      for (int a = 0; a < 3; a++) { /* :133 inc = -H_se2_inv_J_se2_T * res */
+        for (int i = 0; i < ORC_LSSD_PATTERN; i++) prod[i] = (-dp->HinvJT[a][i]) * res[i];
+        inc[a] = lssd_sum(prod, mode);
+      }
+      /* Sophus::SE2f::exp(inc) */
+      const float theta = inc[2];
+      float sn, cs;
+      lssd_sincos(theta, mode, &sn, &cs);
+      float sbt, omcbt;
+      if (fabsf(theta) < 1e-5f) { /* Sophus::Constants<float>::epsilon() */
+        const float theta_sq = theta * theta;
+        sbt = 1.f - (1.f / 6.f) * theta_sq;
+        omcbt = 0.5f * theta - (1.f / 24.f) * theta * theta_sq;
+      } else {
+        sbt = sn / theta;
+        omcbt = (1.f - cs) / theta;
+      }
+      const float ex = sbt * inc[0] - omcbt * inc[1];
+      const float ey = omcbt * inc[0] + sbt * inc[1];
+      /* :134 transform *= SE2::exp(inc).matrix(): (2x3) * (3x3), last row of the right factor (0 0 1) */
+      const float R[3][3] = {{cs, -sn, ex}, {sn, cs, ey}, {0.f, 0.f, 1.f}};
+      float nL[2][2], nt[2];
+      for (int r = 0; r < 2; r++) {
+        for (int c = 0; c < 2; c++) nL[r][c] = (L[r][0] * R[0][c] + L[r][1] * R[1][c]) + t[r] * R[2][c];
+        nt[r] = (L[r][0] * R[0][2] + L[r][1] * R[1][2]) + t[r] * R[2][2];
+      }
+      memcpy(L, nL, sizeof(nL));
+      t[0] = nt[0];
+      t[1] = nt[1];
+      if (!lssd_in_bounds(img2, t[0], t[1], 2.f)) patch_valid = 0; /* :136-139 filter_margin */
+    } else {
+      patch_valid = 0;
+    }
+  }
+  return patch_valid;
+}
+
+/* ref: frame_to_frame_optical_flow_single_thread.cpp:84-112 TrackPoint */
+int orc_lssd_track_point(const orc_pyramid16* old_pyr, const orc_pyramid16* pyr, const float* xy_in,
+                         float* xy_out, int levels, int max_iterations, int mode) {
+  float L[2][2] = {{1.f, 0.f}, {0.f, 1.f}};
+  float t[2] = {xy_out[0], xy_out[1]}; /* transform starts as the caller's initial guess */
+  int patch_valid = 1;
+  for (int level = levels; level >= 0 && patch_valid; level--) {
+    const float scale = (float)(1 << level);
+    t[0] /= scale;
+    t[1] /= scale;
+    lssd_patch p;
+    lssd_patch_set(&p, &old_pyr->lv[level], xy_in[0] / scale, xy_in[1] / scale, mode);
+    patch_valid &= lssd_track_at_level(&pyr->lv[level], &p, L, t, max_iterations, mode);
+    t[0] *= scale;
+    t[1] *= scale;
+  }
+  xy_out[0] = t[0];
+  xy_out[1] = t[1];
+  return patch_valid;
+}
+
+void orc_lssd_tracker_init(orc_lssd_tracker* t, double max_recovered_dist, int32_t levels,
+                           int32_t max_iterations, int mode) {
+  memset(t, 0, sizeof(*t));
+  t->optical_flow_max_recovered_dist = max_recovered_dist;
+  t->optical_flow_levels = levels;
+  t->optical_flow_max_iterations = max_iterations;
+  t->mode = mode;
+}
+
+void orc_lssd_tracker_free(orc_lssd_tracker* t) {
+  if (t->has_old) orc_lssd_free_pyramid(&t->old_pyr);
+  t->has_old = 0;
+}
+
+/* ref: FeatureTrackerLSSDLucasKanade.cpp:35-119 + TrackPoints (frame_to_frame_..._single_thread.cpp:11-82).
+ * The per-id transform map of the reference holds translation = float(position) for every id of the
+ * database (its linear part is reset to identity at the start of each TrackPoint and never read). */
+int orc_lssd_tracker_track(orc_lssd_tracker* t, const uint8_t* cur, int w, int h, int stride,
+                           uint64_t* ids, double* xy, uint32_t* age, int* n_inout) {
+  orc_pyramid16 pyr;
+  if (orc_lssd_build_pyramid(cur, w, h, stride, t->optical_flow_levels, &pyr)) return -1;
+  if (!t->has_old) { /* :57-68 */
+    t->old_pyr = pyr;
+    t->has_old = 1;
+    return 0;
+  }
+  const int n0 = *n_inout;
+  int n = 0;
+  for (int i = 0; i < n0; i++) {
+    const float p1[2] = {(float)xy[2 * i], (float)xy[2 * i + 1]};
+    float p2[2] = {p1[0], p1[1]};
+    int valid = orc_lssd_track_point(&t->old_pyr, &pyr, p1, p2, t->optical_flow_levels,
+                                     t->optical_flow_max_iterations, t->mode);
+    if (valid) {
+      float rec[2] = {p2[0], p2[1]};
+      valid = orc_lssd_track_point(&pyr, &t->old_pyr, p2, rec, t->optical_flow_levels,
+                                   t->optical_flow_max_iterations, t->mode);
+      if (valid) {
+        const float ddx = p1[0] - rec[0], ddy = p1[1] - rec[1];
+        const float dist2 = ddx * ddx + ddy * ddy;
+        valid = (double)dist2 < t->optical_flow_max_recovered_dist; /* :67 */
+      }
+    }
+    if (valid) {
+      ids[n] = ids[i];
+      xy[2 * n] = (double)p2[0]; /* :108 translation().cast<double>() */
+      xy[2 * n + 1] = (double)p2[1];
+      age[n] = age[i];
+      n++;
+    }
+  }
+  *n_inout = n;
+  orc_lssd_free_pyramid(&t->old_pyr);
+  t->old_pyr = pyr;
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* frontend step: bearings, aged count, keyframe decision                                      */
 /* ------------------------------------------------------------------------------------------ */
 int orc_ds_unproject(const orc_camera_ds* cam, double u, double v, double* out3) {
@@ -1230,4 +1651,14 @@ int orc_step_streams(orc_tracker* trackers, orc_detector* detectors, int streams
     }
   }
   return rc_all;
+}
+
+/* test hook: the 3x3 LDLT inverse used by the LSSD patch */
+void orc_lssd_debug_inverse3(const float* H9, float* Hinv9) {
+  float H[3][3], Hi[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) H[i][j] = H9[3 * i + j];
+  lssd_ldlt_inverse3(H, Hi);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Hinv9[3 * i + j] = Hi[i][j];
 }

@@ -154,6 +154,54 @@ int orc_anms_detector_update(orc_anms_detector* d, const uint8_t* img, int w, in
                              const uint8_t* mask, int mask_stride, uint64_t* ids, double* xy,
                              uint32_t* age, int* n_inout, int capacity);
 
+/* ---- LSSD SE(2) patch tracker (ref: src/vslam/feature/FeatureTrackerLSSDLucasKanade.cpp,
+ *      LSSDOpticalFlow/frame_to_frame_optical_flow_single_thread.cpp, patch.h, patterns.h) ----
+ * In-repo parts (TrackPoints / TrackPoint / TrackPointAtLevel, OpticalFlowPatch, Pattern24) are followed
+ * line by line.  The parts that live in the absent basalt-headers / Sophus / Eigen submodules are
+ * restated from their published sources as recalled: Image::InBounds / interp /
+ * interpGrad, ManagedImagePyr::setFromImage (u16 mip levels, floor-half sizes, [1 4 6 4 1]^2 with
+ * one rounding), Sophus::SE2f::exp, Eigen's 3x3 LDLT solve and fixed-size products.  PARITY UNPINNED.
+ * Float summation order:
+ *   ORC_LSSD_SEQ  : sums over the pattern in index order, libm sinf/cosf ("restated reference");
+ *   ORC_LSSD_TREE : sums as a 32-slot butterfly tree (slot i = pattern point i, zeros elsewhere;
+ *                   steps i^1, i^2, i^4, i^8, i^16) and a polynomial sin/cos, which a 32-lane
+ *                   half-wavefront reproduces bit for bit. */
+#define ORC_LSSD_SEQ 0
+#define ORC_LSSD_TREE 1
+#define ORC_LSSD_PATTERN 24
+
+typedef struct {
+  int w, h;
+  uint16_t* data; /* dense, stride == w */
+} orc_level16;
+typedef struct {
+  int levels; /* optical_flow_levels: images 0..levels */
+  orc_level16 lv[ORC_MAX_LEVELS];
+} orc_pyramid16;
+
+/* u8 frame -> u16 (<< 8, FeatureTrackerLSSDLucasKanade.cpp:42-51) -> ManagedImagePyr::setFromImage */
+int orc_lssd_build_pyramid(const uint8_t* img, int w, int h, int stride, int levels, orc_pyramid16* out);
+void orc_lssd_free_pyramid(orc_pyramid16* p);
+/* FrameToFrameOpticalFlow::TrackPoint (forward only): returns validity, xy_out = translation */
+int orc_lssd_track_point(const orc_pyramid16* old_pyr, const orc_pyramid16* pyr, const float* xy_in,
+                         float* xy_out, int levels, int max_iterations, int mode);
+
+typedef struct {
+  double optical_flow_max_recovered_dist; /* 0.09, compared with the SQUARED distance (:67) */
+  int32_t optical_flow_max_iterations;    /* 5 */
+  int32_t optical_flow_levels;            /* 3 */
+  int mode;
+  orc_pyramid16 old_pyr;
+  int has_old;
+} orc_lssd_tracker;
+
+void orc_lssd_tracker_init(orc_lssd_tracker* t, double max_recovered_dist, int32_t levels,
+                           int32_t max_iterations, int mode);
+void orc_lssd_tracker_free(orc_lssd_tracker* t);
+/* FeatureTrackerLSSDLucasKanade::Track (:35-119): first call stores the pyramid only. */
+int orc_lssd_tracker_track(orc_lssd_tracker* t, const uint8_t* cur, int w, int h, int stride,
+                           uint64_t* ids, double* xy, uint32_t* age, int* n_inout);
+
 /* ---- frontend step around the path (ref: src/vslam/frontend/KimeraFrontend.cpp:247-304) ---- */
 typedef struct {
   double fx, fy, cx, cy, xi, alpha; /* DoubleSphereCameraModel (src/vslam/data/Camera.hpp:134) */

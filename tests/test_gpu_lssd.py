@@ -1,0 +1,140 @@
+"""GPU parity of the LSSD SE(2) patch tracker (FeatureTrackerLSSDLucasKanade) against the oracle in
+its LSSD_TREE mode (half-wavefront butterfly sums, polynomial sin/cos), through the C ABI.
+Bar: bit-exact (u16 pyramid, float positions, validity, table order).  The tolerance to the
+pattern-order restatement (LSSD_SEQ) is checked beside it: median 1e-3 px, as the oracle test
+states.  PARITY UNPINNED against the reference itself (no vectors, basalt absent)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _params(vsf, w, h, **kw):
+    return vsf.default_params(tracker_kind=vsf.TRACKER_LSSD, width=w, height=h, **kw)
+
+
+@pytest.mark.parametrize("w,h,levels", [(752, 480, 3), (321, 243, 4), (64, 48, 2), (130, 67, 3)])
+def test_pyramid_bit_exact(vsf, oracle, w, h, levels):
+    rng = np.random.default_rng(w + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ctx = vsf.Context(_params(vsf, w, h, lssd_levels=levels))
+    got = ctx.debug_lssd_pyramid(img)
+    ref = oracle.lssd_build_pyramid(img, levels)
+    for l in range(1, levels + 1):
+        assert np.array_equal(got[l - 1], ref[l]), "level %d" % l
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,levels,iters", [(752, 480, 3, 5), (320, 240, 3, 5), (321, 243, 4, 8), (160, 120, 0, 5),
+                                              (200, 150, 1, 1)])
+def test_points_bit_exact(vsf, oracle, synth, w, h, levels, iters):
+    frames, _ = synth.sequence(900 + w, w, h, 2)
+    kp = oracle.good_features_to_track(frames[0], 301, 0.005, 5.0)
+    rng = np.random.default_rng(1)
+    extra = np.array([[0.0, 0.0], [w - 1.0, h - 1.0], [-3.0, 10.0], [w + 5.0, 10.0], [5.9, 5.9], [6.0, 6.0],
+                      [w - 8.0, h - 8.0], [w / 2 + 0.25, h / 2 + 0.75], [1e6, 1e6], [2.5, h / 2]], np.float32)
+    pts = np.concatenate([kp + rng.uniform(-0.5, 0.5, kp.shape).astype(np.float32), extra]).astype(np.float32)
+    ctx = vsf.Context(_params(vsf, w, h, lssd_levels=levels, lssd_max_iterations=iters))
+    for a, b in ((0, 1), (1, 0), (0, 0)):
+        got, ok = ctx.debug_lssd(frames[a], frames[b], pts)
+        ref, rok = oracle.lssd_track_points(frames[a], frames[b], pts, levels, iters, oracle.LSSD_TREE)
+        assert np.array_equal(ok, rok)
+        v = ok.astype(bool)
+        assert np.array_equal(got[v], ref[v])
+        seq, sok = oracle.lssd_track_points(frames[a], frames[b], pts, levels, iters, oracle.LSSD_SEQ)
+        both = v & sok.astype(bool)
+        if both.sum() > 20:
+            assert np.median(np.abs(got - seq)[both]) < 1e-3
+    # n = 1, n = 0
+    got, ok = ctx.debug_lssd(frames[0], frames[1], pts[:1])
+    ref, rok = oracle.lssd_track_points(frames[0], frames[1], pts[:1], levels, iters, oracle.LSSD_TREE)
+    assert np.array_equal(ok, rok) and (not ok[0] or np.array_equal(got, ref))
+    got, ok = ctx.debug_lssd(frames[0], frames[1], np.zeros((0, 2), np.float32))
+    assert len(ok) == 0
+    ctx.close()
+
+
+@pytest.mark.parametrize("w,h,maxn", [(752, 480, 300), (320, 240, 150), (401, 303, 255)])
+def test_sequence_bit_exact(vsf, oracle, synth, w, h, maxn):
+    """FeatureDetectorShiTomasiBucketing + FeatureTrackerLSSDLucasKanade over a sequence."""
+    frames, _ = synth.sequence(41 + w, w, h, 6)
+    P = vsf.FeatureTrackerLSSDLucasKanade.Parameter()
+    trk = vsf.FeatureTrackerLSSDLucasKanade(P, w, h, capacity=512)
+    det = vsf.FeatureDetectorShiTomasiBucketing(3, 3, maxn, 6.0, w, h, capacity=512)
+    db = vsf.FeatureDatabase(512)
+    otrk = oracle.LssdTracker(P.optical_flow_max_recovered_dist_, P.optical_flow_levels_,
+                              P.optical_flow_max_iterations_, oracle.LSSD_TREE)
+    odet = oracle.Detector(3, 3, maxn, 6.0)
+    T = oracle.FeatureTable(512)
+    for t, fr in enumerate(frames):
+        trk.Track(db, fr)
+        assert otrk.track(T, fr) == 0
+        assert db.n == T.n.value, "step %d" % t
+        assert np.array_equal(db.ids[:db.n], T.ids[:db.n])
+        assert np.array_equal(db.xy[:db.n], T.xy[:db.n])
+        assert np.array_equal(db.age[:db.n], T.age[:db.n])
+        if t:
+            n_in = trk.last_stats[0]
+            assert n_in >= db.n > 0
+        det.UpdateDetection(db, fr)
+        odet.update_detection(T, fr)
+        assert db.n == T.n.value and np.array_equal(db.xy[:db.n], T.xy[:db.n])
+
+
+def test_batch_matches_per_stream_oracle(vsf, oracle, synth):
+    import torch
+    w, h, B, T = 320, 240, 11, 4
+    frames = np.stack([synth.sequence(500 + b, w, h, T)[0] for b in range(B)], 1)  # [T][B][H][W]
+    p = _params(vsf, w, h, grid_rows=2, grid_cols=3, max_features=120, min_distance=7.0, streams=B, capacity=192)
+    ctx = vsf.Context(p)
+    dev = torch.from_numpy(frames).cuda()
+    dets = [oracle.Detector(2, 3, 120, 7.0) for _ in range(B)]
+    trks = [oracle.LssdTracker(mode=oracle.LSSD_TREE) for _ in range(B)]
+    tabs = [oracle.FeatureTable(192) for _ in range(B)]
+    for t in range(T):
+        ctx.batch_step(dev[t].data_ptr(), h * w, w, torch.cuda.current_stream().cuda_stream)
+        ids, xy, age, n, stats = ctx.batch_download()
+        for b in range(B):
+            trks[b].track(tabs[b], frames[t, b])
+            dets[b].update_detection(tabs[b], frames[t, b])
+            e = tabs[b].as_dict()
+            got = {int(i): (float(q[0]), float(q[1]), int(a)) for i, q, a in zip(ids[b, :n[b]], xy[b, :n[b]], age[b, :n[b]])}
+            assert got == e, "step %d stream %d" % (t, b)
+    assert (ctx.batch_status() == 0).all()
+    ctx.close()
+
+
+def test_errors_and_edges(vsf, oracle, synth):
+    w, h = 160, 120
+    with pytest.raises(vsf.VsfError):
+        vsf.Context(_params(vsf, w, h, lssd_levels=8))
+    with pytest.raises(vsf.VsfError):
+        vsf.Context(_params(vsf, w, h, lssd_levels=-1))
+    with pytest.raises(vsf.VsfError):
+        vsf.Context(vsf.default_params(tracker_kind=7, width=w, height=h))
+    ctx = vsf.Context(_params(vsf, w, h))
+    frames, _ = synth.sequence(3, w, h, 2)
+    ids, xy, age = np.zeros(ctx.capacity, np.uint64), np.zeros((ctx.capacity, 2)), np.zeros(ctx.capacity, np.uint32)
+    with pytest.raises(vsf.VsfError):   # the LSSD tracker has no frame-pair Track
+        ctx.track_pair(frames[0], frames[1], ids, xy, age, 0)
+    # empty table through both calls; flat frames drop everything that leaves or cannot be solved
+    n, _ = ctx.track(frames[0], ids, xy, age, 0)
+    assert n == 0
+    n, _ = ctx.track(frames[1], ids, xy, age, 0)
+    assert n == 0
+    flat = np.full((h, w), 90, np.uint8)
+    xy[:3] = [[50, 50], [80.5, 60.25], [20, 100]]
+    ids[:3] = [1, 2, 3]
+    T = oracle.FeatureTable(8)
+    T.set(ids[:3].copy(), xy[:3].copy(), age[:3].copy())
+    ot = oracle.LssdTracker(mode=oracle.LSSD_TREE)
+    ot.track(T, frames[1])
+    ot.track(T, flat)
+    n, _ = ctx.track(flat, ids, xy, age, 3)
+    assert n == T.n.value and np.array_equal(xy[:n], T.xy[:n])
+    # a context without the LSSD tracker refuses the LSSD debug calls
+    lk = vsf.Context(vsf.default_params(width=w, height=h))
+    with pytest.raises(vsf.VsfError):
+        lk.debug_lssd(frames[0], frames[1], np.zeros((2, 2), np.float32))
+    lk.close()
+    ctx.close()

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "vsf_batch_upload", "vsf_batch_download", "vsf_batch_device_tables", "vsf_batch_status",
     "vsf_batch_export_tracks",
     "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig", "vsf_debug_anms",
-    "vsf_batch_frontend_post_track", "vsf_unproject",
+    "vsf_batch_frontend_post_track", "vsf_unproject", "vsf_debug_lssd", "vsf_debug_lssd_pyramid",
     "vsf_profile_enable", "vsf_profile_read",
 ]
 
@@ -43,11 +43,15 @@ class VsfParams(C.Structure):
         ("detector_kind", C.c_int32), ("anms_detection_features", C.c_int32),
         ("anms_quality_level", C.c_double), ("anms_block_size", C.c_int32),
         ("anms_ignore_edge", C.c_int32), ("anms_tolerance", C.c_double),
+        ("tracker_kind", C.c_int32), ("lssd_levels", C.c_int32), ("lssd_max_iterations", C.c_int32),
+        ("lssd_max_recovered_dist", C.c_double),
     ]
 
 
 DETECTOR_BUCKETING = 0
 DETECTOR_ANMS = 1
+TRACKER_LK = 0
+TRACKER_LSSD = 1
 
 
 class VsfCameraDS(C.Structure):
@@ -278,6 +282,26 @@ class Context:
         rx, ry, rw, rh = [int(v) for v in rect]
         return out[:rw * rh].reshape(rh, rw).copy(), (rx, ry, rw, rh)
 
+    def debug_lssd(self, prev, nxt, pts):
+        prev = np.ascontiguousarray(prev, np.uint8)
+        nxt = np.ascontiguousarray(nxt, np.uint8)
+        h, w = prev.shape
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 2)
+        out = np.zeros_like(pts)
+        ok = np.zeros(len(pts), np.uint8)
+        self._chk(lib().vsf_debug_lssd(self._h, _vp(prev), _vp(nxt), w, h, _vp(pts), _vp(out), _vp(ok), len(pts)))
+        return out, ok
+
+    def debug_lssd_pyramid(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = []
+        for l in range(1, self.params.lssd_levels + 1):
+            lv = np.zeros((h >> l, w >> l), np.uint16)
+            self._chk(lib().vsf_debug_lssd_pyramid(self._h, _vp(img), w, h, w, l, _vp(lv)))
+            out.append(lv)
+        return out
+
     # ---- frontend step around the path ----
     def frontend_post_track(self, cam, kp, dt_since_keyframe, d_bearings, stream=0):
         """KimeraFrontend.cpp:247-304 on every stream: bearings into the device buffer `d_bearings`
@@ -397,6 +421,32 @@ class FeatureDetectorANMS:
     @property
     def max_feature_index_(self):
         return self.ctx.get_max_feature_index()
+
+
+class FeatureTrackerLSSDLucasKanade:
+    """Mirror of vslam::feature::FeatureTrackerLSSDLucasKanade (ref: FeatureTrackerLSSDLucasKanade.cpp:13-119):
+    Parameter fields by their reference names, 3-argument Track."""
+
+    class Parameter:
+        def __init__(self):  # FeatureTrackerLSSDLucasKanade.cpp:13-23
+            self.optical_flow_type_ = "frame_to_frame"
+            self.optical_flow_detection_grid_size_ = 32
+            self.optical_flow_max_recovered_dist_ = 0.09
+            self.optical_flow_pattern_ = 51  # unused by the frame-to-frame class, which fixes Pattern24
+            self.optical_flow_max_iterations_ = 5
+            self.optical_flow_levels_ = 3
+
+    def __init__(self, parameter, width, height, device_id=0, capacity=1024):
+        p = default_params(tracker_kind=TRACKER_LSSD, lssd_levels=parameter.optical_flow_levels_,
+                           lssd_max_iterations=parameter.optical_flow_max_iterations_,
+                           lssd_max_recovered_dist=parameter.optical_flow_max_recovered_dist_,
+                           width=width, height=height, device_id=device_id, capacity=capacity)
+        self.parameter_ = parameter
+        self.ctx = Context(p)
+        self.last_stats = None
+
+    def Track(self, db, current_frame):
+        db.n, self.last_stats = self.ctx.track(current_frame, db.ids, db.xy, db.age, db.n)
 
 
 class FeatureTrackerLucasKanade:

@@ -93,6 +93,11 @@ struct vsf_ctx {
   int* d_andet = nullptr;                 // [B]
   double2* d_aselxy = nullptr;            // [B][kcap]
   int* d_aselcnt = nullptr;               // [B]
+  // LSSD tracker (tracker_kind == VSF_TRACKER_LSSD): u16 mip levels >= 1, two sets (prev / cur)
+  LssdParams lssd;
+  int l16w[LSSD_MAXL] = {}, l16h[LSSD_MAXL] = {};
+  uint16_t* lssd_pyr[2][LSSD_MAXL] = {};
+  uint16_t* lssd_pair_pyr[2][LSSD_MAXL] = {};  // single-stream debug pair, allocated lazily
   // frontend step (allocated on first use)
   double* d_fe_dt = nullptr;
   int* d_fe_kf = nullptr;
@@ -259,8 +264,68 @@ GridView grid_view(const vsf_ctx* c) {
   return g;
 }
 
+// basalt ManagedImagePyr::setFromImage on `streams` frames: u16 levels 1..levels
+int lssd_build_pyramid(vsf_ctx* c, const FrameRef& f, uint16_t* const* lv, int streams, hipStream_t s) {
+  ProfScope prof(c, VSF_K_PYRAMID, s);
+  for (int l = 1; l <= c->lssd.levels; l++) {
+    const int dw = c->l16w[l], dh = c->l16h[l];
+    if (dw <= 0 || dh <= 0) continue;
+    dim3 grid((dw + 63) / 64, (dh + 3) / 4, streams);
+    if (l == 1)
+      hipLaunchKernelGGL(lssd_subsample_kernel<true>, grid, dim3(256), 0, s, f.ptr, f.sstride, f.pitch, c->l16w[0],
+                         c->l16h[0], lv[1], dw, dh);
+    else
+      hipLaunchKernelGGL(lssd_subsample_kernel<false>, grid, dim3(256), 0, s, lv[l - 1],
+                         (long long)c->l16w[l - 1] * c->l16h[l - 1], c->l16w[l - 1], c->l16w[l - 1], c->l16h[l - 1],
+                         lv[l], dw, dh);
+  }
+  HIPCHK(c, hipGetLastError());
+  return VSF_OK;
+}
+
+Pyr16View make_view16(const vsf_ctx* c, const FrameRef& f, uint16_t* const* lv) {
+  Pyr16View v;
+  memset(&v, 0, sizeof(v));
+  v.base0 = f.ptr;
+  v.sstride0 = f.sstride;
+  v.pitch0 = f.pitch;
+  v.levels = c->lssd.levels;
+  for (int l = 0; l <= c->lssd.levels; l++) {
+    v.w[l] = c->l16w[l];
+    v.h[l] = c->l16h[l];
+    v.lv[l] = l ? lv[l] : nullptr;
+  }
+  return v;
+}
+
+int lssd_track_impl(vsf_ctx* c, const FrameRef& f, int streams, hipStream_t s) {
+  const int nxt = c->cur ^ 1;
+  int rc = lssd_build_pyramid(c, f, c->lssd_pyr[nxt], streams, s);
+  if (rc) return rc;
+  c->track_frame[nxt] = f;
+  if (c->has_prev) {  // ref: FeatureTrackerLSSDLucasKanade.cpp:57-68 -- first call only stores the pyramid
+    const Pyr16View P = make_view16(c, c->track_frame[c->cur], c->lssd_pyr[c->cur]);
+    const Pyr16View C = make_view16(c, f, c->lssd_pyr[nxt]);
+    {
+      ProfScope prof(c, VSF_K_LK, s);
+      int fgrid = (c->p.max_features + 64 + 1) / 2;  // feature pairs per stream
+      if (fgrid > (c->cap + 1) / 2) fgrid = (c->cap + 1) / 2;
+      dim3 grid((unsigned)(8 * fgrid * ((streams + 7) / 8)));
+      hipLaunchKernelGGL(lssd_fb_kernel, grid, dim3(64), 0, s, P, C, c->d_xy, c->d_n, c->cap, fgrid, streams, c->lssd,
+                         c->d_fwd, c->d_flags);
+      HIPCHK(c, hipGetLastError());
+    }
+    rc = launch_compact(c, streams, s);
+    if (rc) return rc;
+  }
+  c->cur = nxt;
+  c->has_prev = true;
+  return VSF_OK;
+}
+
 // Track on `streams` streams given the current frames (already on the device).
 int track_impl(vsf_ctx* c, const FrameRef& f, int streams, hipStream_t s) {
+  if (c->p.tracker_kind == VSF_TRACKER_LSSD) return lssd_track_impl(c, f, streams, s);
   const int nxt = c->cur ^ 1;
   int rc = build_pyramid(c, f, c->track_pyr[nxt], streams, s);
   if (rc) return rc;
@@ -496,6 +561,10 @@ void vsf_default_params(vsf_params* p) {
   p->anms_block_size = 4;
   p->anms_ignore_edge = 20;
   p->anms_tolerance = 0.1;
+  p->tracker_kind = VSF_TRACKER_LK;
+  p->lssd_levels = 3;
+  p->lssd_max_iterations = 5;
+  p->lssd_max_recovered_dist = 0.09;
 }
 
 const char* vsf_last_error(const vsf_ctx* ctx) { return ctx ? ctx->err : "null context"; }
@@ -508,6 +577,10 @@ void vsf_destroy(vsf_ctx* c) {
     for (int l = 0; l < MAXL; l++) {
       if (c->track_pyr[i].lv[l]) (void)hipFree(c->track_pyr[i].lv[l]);
       if (c->pair_pyr[i].lv[l]) (void)hipFree(c->pair_pyr[i].lv[l]);
+    }
+    for (int l = 0; l < LSSD_MAXL; l++) {
+      if (c->lssd_pyr[i][l]) (void)hipFree(c->lssd_pyr[i][l]);
+      if (c->lssd_pair_pyr[i][l]) (void)hipFree(c->lssd_pair_pyr[i][l]);
     }
     if (c->own_frame[i]) (void)hipFree(c->own_frame[i]);
     if (c->pair_frame[i]) (void)hipFree(c->pair_frame[i]);
@@ -550,6 +623,11 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     if (!(p->anms_quality_level >= 0.0) || !(p->anms_tolerance >= 0.0) || p->anms_ignore_edge < 0) return VSF_E_INVALID;
     if (p->width > 32767 || p->height > 32767) return VSF_E_INVALID;  // keypoints travel as short2
   }
+  const bool use_lssd = p->tracker_kind == VSF_TRACKER_LSSD;
+  if (p->tracker_kind != VSF_TRACKER_LK && !use_lssd) return VSF_E_INVALID;
+  if (use_lssd && (p->lssd_levels < 0 || p->lssd_levels >= LSSD_MAXL || p->lssd_max_iterations < 0 ||
+                   (p->width >> p->lssd_levels) < 1 || (p->height >> p->lssd_levels) < 1))
+    return VSF_E_INVALID;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device_id < 0 || p->device_id >= ndev)
     return VSF_E_HIP;  // no GPU: fail loudly, there is no CPU path
@@ -645,6 +723,15 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     c->k_mid = (float)(2.0 * scale);
   }
 
+  if (use_lssd) {
+    c->lssd.levels = p->lssd_levels;
+    c->lssd.max_iterations = p->lssd_max_iterations;
+    c->lssd.max_recovered_dist = p->lssd_max_recovered_dist;
+    for (int l = 0; l <= p->lssd_levels; l++) {  // ManagedImagePyr::lvl(l): (w >> l, h >> l)
+      c->l16w[l] = p->width >> l;
+      c->l16h[l] = p->height >> l;
+    }
+  }
   if (use_anms) {
     AnmsParams& a = c->anms;
     memset(&a, 0, sizeof(a));
@@ -689,7 +776,8 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   do {                          \
     if (!rc) rc = (expr);       \
   } while (0)
-  for (int i = 0; i < 2; i++) A(alloc_pyr(c, &c->track_pyr[i], B));
+  if (!use_lssd)  // the LSSD tracker keeps its own u16 levels
+    for (int i = 0; i < 2; i++) A(alloc_pyr(c, &c->track_pyr[i], B));
   const size_t fs = (size_t)p->width * p->height;
   A(dalloc(c, &c->own_frame[0], fs));
   A(dalloc(c, &c->own_frame[1], fs));
@@ -717,6 +805,9 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   A(dalloc(c, &c->d_lam, (size_t)B * c->lam_total));
   A(dalloc(c, &c->d_selxy, BC * (size_t)(c->grid_max > 0 ? c->grid_max : 1)));
   A(dalloc(c, &c->d_selcnt, BC));
+  if (use_lssd)
+    for (int i = 0; i < 2; i++)
+      for (int l = 1; l <= p->lssd_levels; l++) A(dalloc(c, &c->lssd_pyr[i][l], (size_t)B * c->l16w[l] * c->l16h[l] + 8));
   if (use_anms) {
     A(dalloc(c, &c->d_aflag, (size_t)B * fs));
     A(dalloc(c, &c->d_arect, (size_t)1));
@@ -838,6 +929,8 @@ int vsf_track_pair(vsf_ctx* c, const uint8_t* prev, int32_t prev_stride, const u
                    int32_t w, int32_t h, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout,
                    vsf_track_stats* stats) {
   if (!c || !prev || !cur || !n_inout) return VSF_E_INVALID;
+  if (c->p.tracker_kind == VSF_TRACKER_LSSD)  // the reference's LSSD tracker has the stateful 3-argument Track only
+    return fail(c, VSF_E_INVALID, "vsf_track_pair: FeatureTrackerLSSDLucasKanade has no frame-pair form");
   int rc = check_geom(c, w, h, prev_stride);
   if (!rc) rc = check_geom(c, w, h, cur_stride);
   if (rc) return rc;
@@ -1151,6 +1244,69 @@ int vsf_unproject(vsf_ctx* c, const vsf_camera_ds* cam, const double* xy, int32_
   if (d_ok) (void)hipFree(d_ok);
   if (rc == VSF_E_HIP) return fail(c, rc, "vsf_unproject: HIP failure");
   return rc;
+}
+
+namespace {
+int lssd_ensure_pair(vsf_ctx* c) {
+  int rc = ensure_pair(c);
+  for (int i = 0; i < 2 && !rc; i++)
+    for (int l = 1; l <= c->lssd.levels && !rc; l++)
+      if (!c->lssd_pair_pyr[i][l]) rc = dalloc(c, &c->lssd_pair_pyr[i][l], (size_t)c->l16w[l] * c->l16h[l] + 8);
+  return rc;
+}
+}  // namespace
+
+int vsf_debug_lssd(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w, int32_t h, const float* prev_pts,
+                   float* next_pts, uint8_t* valid, int32_t n) {
+  if (!c || !prev || !next || n < 0 || (n > 0 && (!prev_pts || !next_pts || !valid))) return VSF_E_INVALID;
+  if (c->p.tracker_kind != VSF_TRACKER_LSSD) return fail(c, VSF_E_INVALID, "not an LSSD context");
+  int rc = check_geom(c, w, h, w);
+  if (rc) return rc;
+  if (n == 0) return VSF_OK;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  rc = lssd_ensure_pair(c);
+  if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, w);
+  if (!rc) rc = upload_frame(c, c->pair_frame[1], next, w, h, w);
+  if (rc) return rc;
+  float2 *d_in = nullptr, *d_out = nullptr;
+  uint8_t* d_ok = nullptr;
+  rc = dalloc(c, &d_in, (size_t)n);
+  if (!rc) rc = dalloc(c, &d_out, (size_t)n);
+  if (!rc) rc = dalloc(c, &d_ok, (size_t)n);
+  if (!rc && hipMemcpy(d_in, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = VSF_E_HIP;
+  const FrameRef fp = own_ref(c, c->pair_frame[0]), fc = own_ref(c, c->pair_frame[1]);
+  if (!rc) rc = lssd_build_pyramid(c, fp, c->lssd_pair_pyr[0], 1, nullptr);
+  if (!rc) rc = lssd_build_pyramid(c, fc, c->lssd_pair_pyr[1], 1, nullptr);
+  if (!rc) {
+    const Pyr16View P = make_view16(c, fp, c->lssd_pair_pyr[0]), C = make_view16(c, fc, c->lssd_pair_pyr[1]);
+    hipLaunchKernelGGL(lssd_points_kernel, dim3((n + 1) / 2), dim3(64), 0, nullptr, P, C, d_in, n, c->lssd, d_out, d_ok);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) rc = VSF_E_HIP;
+  }
+  if (!rc && hipMemcpy(next_pts, d_out, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
+  if (!rc && hipMemcpy(valid, d_ok, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (d_ok) (void)hipFree(d_ok);
+  if (rc == VSF_E_HIP) return fail(c, rc, "vsf_debug_lssd: HIP failure");
+  return rc;
+}
+
+int vsf_debug_lssd_pyramid(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t level,
+                           uint16_t* out) {
+  if (!c || !img || !out) return VSF_E_INVALID;
+  if (c->p.tracker_kind != VSF_TRACKER_LSSD) return fail(c, VSF_E_INVALID, "not an LSSD context");
+  if (level < 1 || level > c->lssd.levels) return VSF_E_INVALID;
+  int rc = check_geom(c, w, h, stride);
+  if (rc) return rc;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  rc = lssd_ensure_pair(c);
+  if (!rc) rc = upload_frame(c, c->pair_frame[0], img, w, h, stride);
+  if (!rc) rc = lssd_build_pyramid(c, own_ref(c, c->pair_frame[0]), c->lssd_pair_pyr[0], 1, nullptr);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(nullptr));
+  HIPCHK(c, hipMemcpy(out, c->lssd_pair_pyr[0][level], (size_t)c->l16w[level] * c->l16h[level] * 2,
+                      hipMemcpyDeviceToHost));
+  return VSF_OK;
 }
 
 int vsf_debug_anms(vsf_ctx* c, int32_t stream, uint8_t* flag_out, int16_t* kp_out, int32_t* n_kp_out) {

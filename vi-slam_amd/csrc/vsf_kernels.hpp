@@ -1660,3 +1660,4 @@ __global__ __launch_bounds__(256) void export_kernel(const uint64_t* __restrict_
 
 }  // namespace vsf
 #include "vsf_anms.hpp"
+#include "vsf_lssd.hpp"

@@ -1,0 +1,411 @@
+// vsf_lssd.hpp -- FeatureTrackerLSSDLucasKanade on the device (ref: src/vslam/feature/
+// FeatureTrackerLSSDLucasKanade.cpp:35-119, LSSDOpticalFlow/frame_to_frame_optical_flow_single_thread.cpp,
+// patch.h, patterns.h): basalt's frame-to-frame SE(2) patch tracker with Pattern24, float arithmetic,
+// forward + backward tracking and the recovered-distance test.
+// One 32-lane half-wavefront per feature, lane i = pattern point i (24 of 32 lanes carry a point).
+// Every sum over the pattern is a 32-slot butterfly (xor 1, 2, 4, 8, 16) -- the order the oracle's
+// ORC_LSSD_TREE mode uses -- and every other expression is written exactly as in oracle/vsf_oracle.c,
+// so the results are equal bit for bit (the build uses -ffp-contract=off; float division and sqrt are
+// correctly rounded).  Included by vsf_kernels.hpp.
+#pragma once
+
+namespace vsf {
+
+constexpr int LSSD_PATTERN = 24;
+constexpr int LSSD_MAXL = 8;
+
+// ref: LSSDOpticalFlow/patterns.h:60-73 (Pattern24::pattern_raw)
+__device__ const float LSSD_PAT[32][2] = {
+    {-1, 5},  {1, 5},  {-3, 3},  {-1, 3},  {1, 3},   {3, 3},   {-5, 1},  {-3, 1}, {-1, 1}, {1, 1}, {3, 1},
+    {5, 1},   {-5, -1}, {-3, -1}, {-1, -1}, {1, -1}, {3, -1},  {5, -1},  {-3, -3}, {-1, -3}, {1, -3}, {3, -3},
+    {-1, -5}, {1, -5}, {0, 0},   {0, 0},   {0, 0},   {0, 0},   {0, 0},   {0, 0},  {0, 0},  {0, 0}};
+
+// u16 mip pyramid of `streams` frames: level 0 is the caller's u8 frame read as (v << 8)
+// (FeatureTrackerLSSDLucasKanade.cpp:42-51), levels >= 1 are dense u16 [stream][h][w].
+struct Pyr16View {
+  const uint8_t* base0;
+  long long sstride0;
+  int pitch0;
+  const uint16_t* lv[LSSD_MAXL];
+  int w[LSSD_MAXL], h[LSSD_MAXL];
+  int levels;  // optical_flow_levels: images 0..levels
+};
+
+struct LssdParams {
+  int levels;
+  int max_iterations;
+  double max_recovered_dist;  // compared with the SQUARED distance (frame_to_frame_..._single_thread.cpp:67)
+};
+
+// basalt::ManagedImagePyr<uint16_t>::subsample: [1 4 6 4 1]^2 in int, REFLECT_101, (v + 128) >> 8, size (w/2, h/2).
+// SRC8: source is the u8 frame read as v << 8.
+template <bool SRC8>
+__global__ __launch_bounds__(256) void lssd_subsample_kernel(const void* __restrict__ src, long long src_sstride,
+                                                             int src_pitch, int sw, int sh,
+                                                             uint16_t* __restrict__ dst, int dw, int dh) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int stream = blockIdx.z;
+  if (x >= dw || y >= dh) return;
+  const int k[5] = {1, 4, 6, 4, 1};
+  int acc = 0;
+#pragma unroll
+  for (int j = -2; j <= 2; j++) {
+    const int yy = reflect101(2 * y + j, sh);
+    int r = 0;
+#pragma unroll
+    for (int i = -2; i <= 2; i++) {
+      const int xx = reflect101(2 * x + i, sw);
+      int v;
+      if (SRC8)
+        v = (int)(reinterpret_cast<const uint8_t*>(src) + (long long)stream * src_sstride)[(long long)yy * src_pitch + xx] << 8;
+      else
+        v = (int)(reinterpret_cast<const uint16_t*>(src) + (long long)stream * src_sstride)[(long long)yy * src_pitch + xx];
+      r += k[i + 2] * v;
+    }
+    acc += k[j + 2] * r;
+  }
+  dst[((long long)stream * dh + y) * dw + x] = (uint16_t)((acc + (1 << 7)) >> 8);
+}
+
+struct Lvl16 {  // one level of one stream
+  const uint8_t* p8;
+  const uint16_t* p16;
+  int pitch, w, h;
+};
+__device__ __forceinline__ Lvl16 lssd_level(const Pyr16View& P, int stream, int level) {
+  Lvl16 L;
+  L.w = P.w[level];
+  L.h = P.h[level];
+  if (level == 0) {
+    L.p8 = P.base0 + (long long)stream * P.sstride0;
+    L.p16 = nullptr;
+    L.pitch = P.pitch0;
+  } else {
+    L.p8 = nullptr;
+    L.p16 = P.lv[level] + (long long)stream * L.w * L.h;
+    L.pitch = L.w;
+  }
+  return L;
+}
+__device__ __forceinline__ float lssd_px(const Lvl16& im, int x, int y) {
+  if (im.p8) return (float)((int)im.p8[(long long)y * im.pitch + x] << 8);
+  return (float)im.p16[(long long)y * im.pitch + x];
+}
+// basalt::Image::InBounds(p, border), floating point p
+__device__ __forceinline__ bool lssd_in_bounds(const Lvl16& im, float x, float y, float border) {
+  return border <= x && x < ((float)im.w - border - 1.f) && border <= y && y < ((float)im.h - border - 1.f);
+}
+// basalt::Image::interp<float>
+__device__ __forceinline__ float lssd_interp(const Lvl16& im, float x, float y) {
+  const int ix = (int)x, iy = (int)y;
+  const float dx = x - (float)ix, dy = y - (float)iy;
+  const float ddx = 1.f - dx, ddy = 1.f - dy;
+  return ddx * ddy * lssd_px(im, ix, iy) + ddx * dy * lssd_px(im, ix, iy + 1) + dx * ddy * lssd_px(im, ix + 1, iy) +
+         dx * dy * lssd_px(im, ix + 1, iy + 1);
+}
+// basalt::Image::interpGrad<float>
+__device__ __forceinline__ void lssd_interp_grad(const Lvl16& im, float x, float y, float (&out)[3]) {
+  const int ix = (int)x, iy = (int)y;
+  const float dx = x - (float)ix, dy = y - (float)iy;
+  const float ddx = 1.f - dx, ddy = 1.f - dy;
+  const float px0y0 = lssd_px(im, ix, iy), px1y0 = lssd_px(im, ix + 1, iy);
+  const float px0y1 = lssd_px(im, ix, iy + 1), px1y1 = lssd_px(im, ix + 1, iy + 1);
+  out[0] = ddx * ddy * px0y0 + ddx * dy * px0y1 + dx * ddy * px1y0 + dx * dy * px1y1;
+  const float pxm1y0 = lssd_px(im, ix - 1, iy), pxm1y1 = lssd_px(im, ix - 1, iy + 1);
+  const float res_mx = ddx * ddy * pxm1y0 + ddx * dy * pxm1y1 + dx * ddy * px0y0 + dx * dy * px0y1;
+  const float px2y0 = lssd_px(im, ix + 2, iy), px2y1 = lssd_px(im, ix + 2, iy + 1);
+  const float res_px = ddx * ddy * px1y0 + ddx * dy * px1y1 + dx * ddy * px2y0 + dx * dy * px2y1;
+  out[1] = 0.5f * (res_px - res_mx);
+  const float px0ym1 = lssd_px(im, ix, iy - 1), px1ym1 = lssd_px(im, ix + 1, iy - 1);
+  const float res_my = ddx * ddy * px0ym1 + ddx * dy * px0y0 + dx * ddy * px1ym1 + dx * dy * px1y0;
+  const float px0y2 = lssd_px(im, ix, iy + 2), px1y2 = lssd_px(im, ix + 1, iy + 2);
+  const float res_py = ddx * ddy * px0y1 + ddx * dy * px0y2 + dx * ddy * px1y1 + dx * dy * px1y2;
+  out[2] = 0.5f * (res_py - res_my);
+}
+
+// 32-slot butterfly sum: every lane of the half-wavefront ends with the same value
+__device__ __forceinline__ float lssd_sum32(float v) {
+#pragma unroll
+  for (int step = 1; step < 32; step <<= 1) v = v + __shfl_xor(v, step, 32);
+  return v;
+}
+__device__ __forceinline__ int lssd_count32(bool pred) {
+  const unsigned long long b = __ballot(pred);
+  const unsigned int half = (threadIdx.x & 32) ? (unsigned int)(b >> 32) : (unsigned int)b;
+  return __popc(half);
+}
+
+__device__ __forceinline__ void lssd_sincos(float t, float& s, float& c) {  // oracle lssd_sincos, TREE mode
+  const float t2 = t * t;
+  s = t * (1.f + t2 * (-1.f / 6.f + t2 * (1.f / 120.f + t2 * (-1.f / 5040.f + t2 * (1.f / 362880.f)))));
+  c = 1.f + t2 * (-0.5f + t2 * (1.f / 24.f + t2 * (-1.f / 720.f + t2 * (1.f / 40320.f + t2 * (-1.f / 3628800.f)))));
+}
+
+// Eigen::LDLT<Matrix3f> compute + solveInPlace(Identity), as restated in oracle lssd_ldlt_inverse3
+__device__ inline void lssd_ldlt_inverse3(const float (&H)[3][3], float (&Hinv)[3][3]) {
+  float m[3][3];
+  int tr[3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) m[i][j] = H[i][j];
+  for (int k = 0; k < 3; k++) {
+    int big = k;
+    float bv = fabsf(m[k][k]);
+    for (int i = k + 1; i < 3; i++)
+      if (fabsf(m[i][i]) > bv) {
+        bv = fabsf(m[i][i]);
+        big = i;
+      }
+    tr[k] = big;
+    if (big != k) {
+      const int s = 3 - big - 1;
+      for (int j = 0; j < k; j++) {
+        const float t = m[k][j];
+        m[k][j] = m[big][j];
+        m[big][j] = t;
+      }
+      for (int i = 0; i < s; i++) {
+        const float t = m[big + 1 + i][k];
+        m[big + 1 + i][k] = m[big + 1 + i][big];
+        m[big + 1 + i][big] = t;
+      }
+      {
+        const float t = m[k][k];
+        m[k][k] = m[big][big];
+        m[big][big] = t;
+      }
+      for (int i = k + 1; i < big; i++) {
+        const float t = m[i][k];
+        m[i][k] = m[big][i];
+        m[big][i] = t;
+      }
+    }
+    const int rs = 3 - k - 1;
+    if (k > 0) {
+      float temp[3] = {0.f, 0.f, 0.f};
+      for (int j = 0; j < k; j++) temp[j] = m[j][j] * m[k][j];
+      float dot = 0.f;
+      for (int j = 0; j < k; j++) dot = (j == 0) ? m[k][j] * temp[j] : dot + m[k][j] * temp[j];
+      m[k][k] -= dot;
+      for (int i = 0; i < rs; i++) {
+        float d2 = 0.f;
+        for (int j = 0; j < k; j++) d2 = (j == 0) ? m[k + 1 + i][j] * temp[j] : d2 + m[k + 1 + i][j] * temp[j];
+        m[k + 1 + i][k] -= d2;
+      }
+    }
+    const float akk = m[k][k];
+    if (rs > 0 && fabsf(akk) > 0.f)
+      for (int i = 0; i < rs; i++) m[k + 1 + i][k] /= akk;
+  }
+  float X[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) X[i][j] = (i == j) ? 1.f : 0.f;
+  for (int k = 0; k < 3; k++)
+    if (tr[k] != k)
+      for (int j = 0; j < 3; j++) {
+        const float t = X[k][j];
+        X[k][j] = X[tr[k]][j];
+        X[tr[k]][j] = t;
+      }
+  for (int c = 0; c < 3; c++)
+    for (int i = 1; i < 3; i++)
+      for (int j = 0; j < i; j++) X[i][c] -= m[i][j] * X[j][c];
+  const float tol = 1.f / 3.4028234663852886e+38f;
+  for (int i = 0; i < 3; i++)
+    for (int c = 0; c < 3; c++) {
+      if (fabsf(m[i][i]) > tol)
+        X[i][c] /= m[i][i];
+      else
+        X[i][c] = 0.f;
+    }
+  for (int c = 0; c < 3; c++)
+    for (int i = 1; i >= 0; i--)
+      for (int j = i + 1; j < 3; j++) X[i][c] -= m[j][i] * X[j][c];
+  for (int k = 2; k >= 0; k--)
+    if (tr[k] != k)
+      for (int j = 0; j < 3; j++) {
+        const float t = X[k][j];
+        X[k][j] = X[tr[k]][j];
+        X[tr[k]][j] = t;
+      }
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Hinv[i][j] = X[i][j];
+}
+
+// FrameToFrameOpticalFlow::TrackPoint (frame_to_frame_optical_flow_single_thread.cpp:84-146) for the
+// feature of this half-wavefront.  `active`: the half holds a feature (control flow below is per half:
+// the two halves of a wave may run different trip counts, lanes of a finished half idle).
+__device__ bool lssd_track_point(const Pyr16View& OLD, const Pyr16View& CUR, int stream, bool active, float pinx,
+                                 float piny, float& tx, float& ty, const LssdParams& prm) {
+  const int li = threadIdx.x & 31;
+  const float patx = LSSD_PAT[li][0], paty = LSSD_PAT[li][1];
+  const bool has_pt = li < LSSD_PATTERN;
+  float L00 = 1.f, L01 = 0.f, L10 = 0.f, L11 = 1.f;
+  float t0 = tx, t1 = ty;
+  bool valid = active;
+  for (int level = prm.levels; level >= 0; level--) {
+    if (!__any(valid)) break;
+    const float scale = (float)(1 << level);
+    const Lvl16 im1 = lssd_level(OLD, stream, level), im2 = lssd_level(CUR, stream, level);
+    float data = -1.f, M0 = 0.f, M1 = 0.f, M2 = 0.f;
+    const bool lvl_active = valid;  // the reference leaves the level loop once the patch is invalid
+    float s0 = t0, s1 = t1;         // translation at this level's scale
+    if (lvl_active) {
+      s0 = t0 / scale;
+      s1 = t1 / scale;
+    }
+    // ---- OpticalFlowPatch::setFromImage (patch.h:75-131)
+    {
+      const float x = pinx / scale + patx, y = piny / scale + paty;
+      const bool inb = valid && has_pt && lssd_in_bounds(im1, x, y, 2.f);
+      float val = 0.f, gx = 0.f, gy = 0.f;
+      if (inb) {
+        float vg[3];
+        lssd_interp_grad(im1, x, y, vg);
+        data = vg[0];
+        val = vg[0];
+        gx = vg[1];
+        gy = vg[2];
+      }
+      const int num_valid = lssd_count32(inb);
+      const float sum = lssd_sum32(val), gsx = lssd_sum32(gx), gsy = lssd_sum32(gy);
+      const float mean_inv = (float)num_valid / sum;
+      float jx = 0.f, jy = 0.f;
+      if (data >= 0.f) {
+        const float d = data;
+        jx = ((float)num_valid * (gx * sum - gsx * d)) / (sum * sum);
+        jy = ((float)num_valid * (gy * sum - gsy * d)) / (sum * sum);
+        data = d * mean_inv;
+      }
+      const float J0 = jx, J1 = jy, J2 = jx * (-paty) + jy * patx;
+      float H[3][3], Hinv[3][3];
+      H[0][0] = lssd_sum32(J0 * J0);
+      H[0][1] = H[1][0] = lssd_sum32(J0 * J1);
+      H[0][2] = H[2][0] = lssd_sum32(J0 * J2);
+      H[1][1] = lssd_sum32(J1 * J1);
+      H[1][2] = H[2][1] = lssd_sum32(J1 * J2);
+      H[2][2] = lssd_sum32(J2 * J2);
+      lssd_ldlt_inverse3(H, Hinv);
+      M0 = (Hinv[0][0] * J0 + Hinv[0][1] * J1) + Hinv[0][2] * J2;
+      M1 = (Hinv[1][0] * J0 + Hinv[1][1] * J1) + Hinv[1][2] * J2;
+      M2 = (Hinv[2][0] * J0 + Hinv[2][1] * J1) + Hinv[2][2] * J2;
+      if (!has_pt) {
+        M0 = 0.f;
+        M1 = 0.f;
+        M2 = 0.f;
+      }
+    }
+    // ---- TrackPointAtLevel (:114-146)
+    for (int it = 0; it < prm.max_iterations; it++) {
+      if (!__any(valid)) break;
+      const float px = (L00 * patx + L01 * paty) + s0, py = (L10 * patx + L11 * paty) + s1;
+      const bool inb = valid && has_pt && lssd_in_bounds(im2, px, py, 2.f);
+      float res = -1.f, val = 0.f;
+      if (inb) {
+        res = lssd_interp(im2, px, py);
+        val = res;
+      }
+      const int num_valid = lssd_count32(inb);
+      const float sum = lssd_sum32(val);
+      const bool use = has_pt && res >= 0.f && data >= 0.f;
+      float r = 0.f;
+      if (use) r = ((float)num_valid * res) / sum - data;
+      const int num_res = lssd_count32(use);
+      // slots without a pattern point hold +0 like the oracle's padding (not the -0 of (-0) * 0)
+      const float inc0 = lssd_sum32(has_pt ? (-M0) * r : 0.f), inc1 = lssd_sum32(has_pt ? (-M1) * r : 0.f),
+                  inc2 = lssd_sum32(has_pt ? (-M2) * r : 0.f);
+      if (valid) {
+        if (num_res > LSSD_PATTERN / 2) {
+          const float theta = inc2;  // Sophus::SE2f::exp
+          float sn, cs;
+          lssd_sincos(theta, sn, cs);
+          float sbt, omcbt;
+          if (fabsf(theta) < 1e-5f) {
+            const float theta_sq = theta * theta;
+            sbt = 1.f - (1.f / 6.f) * theta_sq;
+            omcbt = 0.5f * theta - (1.f / 24.f) * theta * theta_sq;
+          } else {
+            sbt = sn / theta;
+            omcbt = (1.f - cs) / theta;
+          }
+          const float ex = sbt * inc0 - omcbt * inc1;
+          const float ey = omcbt * inc0 + sbt * inc1;
+          // transform *= SE2::exp(inc).matrix(): (2x3) * (3x3) with last row (0 0 1)
+          const float n00 = (L00 * cs + L01 * sn) + s0 * 0.f, n01 = (L00 * (-sn) + L01 * cs) + s0 * 0.f;
+          const float n10 = (L10 * cs + L11 * sn) + s1 * 0.f, n11 = (L10 * (-sn) + L11 * cs) + s1 * 0.f;
+          const float nt0 = (L00 * ex + L01 * ey) + s0 * 1.f, nt1 = (L10 * ex + L11 * ey) + s1 * 1.f;
+          L00 = n00;
+          L01 = n01;
+          L10 = n10;
+          L11 = n11;
+          s0 = nt0;
+          s1 = nt1;
+          if (!lssd_in_bounds(im2, s0, s1, 2.f)) valid = false;
+        } else {
+          valid = false;
+        }
+      }
+    }
+    // TrackPoint :98/:106 scale the translation of a level that ran, whatever its outcome
+    if (lvl_active) {
+      t0 = s0 * scale;
+      t1 = s1 * scale;
+    }
+  }
+  tx = t0;
+  ty = t1;
+  return valid;
+}
+
+// flags as lk_fb_kernel: bit0 forward valid, bit1 backward valid, bit2 kept.  Two features per wave.
+__global__ __launch_bounds__(64) void lssd_fb_kernel(Pyr16View P, Pyr16View C, const double2* __restrict__ xy,
+                                                     const int* __restrict__ n, int cap, int fgrid, int nstreams,
+                                                     LssdParams prm, float2* __restrict__ fwd,
+                                                     uint8_t* __restrict__ flags) {
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;  // same XCD-aware map as lk_fb_kernel
+  const int grp = local / fgrid;
+  const int stream = grp * 8 + xcd, pair0 = local - grp * fgrid;
+  if (stream >= nstreams) return;
+  const int nf = n[stream];
+  const int half = (threadIdx.x >> 5) & 1;
+  for (int f0 = 2 * pair0; f0 < nf; f0 += 2 * fgrid) {
+    const int f = f0 + half;
+    const bool active = f < nf;
+    double2 p0 = make_double2(0.0, 0.0);
+    if (active) p0 = xy[(long long)stream * cap + f];
+    const float p1x = (float)p0.x, p1y = (float)p0.y;  // transform.translation() = pos.cast<float>() (:64,:77)
+    float qx = p1x, qy = p1y;
+    uint8_t flag = 0;
+    const bool v1 = lssd_track_point(P, C, stream, active, p1x, p1y, qx, qy, prm);
+    float rx = qx, ry = qy;
+    const bool v2 = lssd_track_point(C, P, stream, v1, qx, qy, rx, ry, prm);
+    if (v1) flag |= 1;
+    if (v2) {
+      flag |= 2;
+      const float ddx = p1x - rx, ddy = p1y - ry;
+      const float dist2 = ddx * ddx + ddy * ddy;
+      if ((double)dist2 < prm.max_recovered_dist) flag |= 4;  // :67
+    }
+    if (active && (threadIdx.x & 31) == 0) {
+      fwd[(long long)stream * cap + f] = make_float2(qx, qy);
+      flags[(long long)stream * cap + f] = flag;
+    }
+  }
+}
+
+// TrackPoint (forward only) on a point list, for parity tests
+__global__ __launch_bounds__(64) void lssd_points_kernel(Pyr16View P, Pyr16View C, const float2* __restrict__ pts, int n,
+                                                         LssdParams prm, float2* __restrict__ out,
+                                                         uint8_t* __restrict__ valid) {
+  const int f = blockIdx.x * 2 + ((threadIdx.x >> 5) & 1);
+  const bool active = f < n;
+  float2 p = make_float2(0.f, 0.f);
+  if (active) p = pts[f];
+  float qx = p.x, qy = p.y;
+  const bool v = lssd_track_point(P, C, 0, active, p.x, p.y, qx, qy, prm);
+  if (active && (threadIdx.x & 31) == 0) {
+    out[f] = make_float2(qx, qy);
+    valid[f] = v ? 1 : 0;
+  }
+}
+
+}  // namespace vsf
