@@ -298,7 +298,8 @@ class _Pyramid16(C.Structure):
 
 class _LssdTracker(C.Structure):
     _fields_ = [("max_recovered_dist", C.c_double), ("max_iterations", C.c_int32), ("levels", C.c_int32),
-                ("mode", C.c_int), ("old_pyr", _Pyramid16), ("has_old", C.c_int)]
+                ("mode", C.c_int), ("old_pyr", _Pyramid16), ("has_old", C.c_int),
+                ("map_ids", C.c_void_p), ("map_xy", C.c_void_p), ("map_n", C.c_int), ("map_cap", C.c_int)]
 
 
 def lssd_build_pyramid(img, levels=3):

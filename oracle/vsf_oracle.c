@@ -1407,24 +1407,56 @@ void orc_lssd_tracker_init(orc_lssd_tracker* t, double max_recovered_dist, int32
 void orc_lssd_tracker_free(orc_lssd_tracker* t) {
   if (t->has_old) orc_lssd_free_pyramid(&t->old_pyr);
   t->has_old = 0;
+  free(t->map_ids);
+  free(t->map_xy);
+  t->map_ids = NULL;
+  t->map_xy = NULL;
+  t->map_n = t->map_cap = 0;
+}
+
+/* transform_ <- the database as it stands (ids, float(position)) */
+static void lssd_map_store(orc_lssd_tracker* t, const uint64_t* ids, const double* xy, int n) {
+  if (n > t->map_cap) {
+    t->map_cap = n + 64;
+    t->map_ids = (uint64_t*)realloc(t->map_ids, sizeof(uint64_t) * (size_t)t->map_cap);
+    t->map_xy = (float*)realloc(t->map_xy, sizeof(float) * 2 * (size_t)t->map_cap);
+  }
+  for (int i = 0; i < n; i++) {
+    t->map_ids[i] = ids[i];
+    t->map_xy[2 * i] = (float)xy[2 * i];
+    t->map_xy[2 * i + 1] = (float)xy[2 * i + 1];
+  }
+  t->map_n = n;
 }
 
 /* ref: FeatureTrackerLSSDLucasKanade.cpp:35-119 + TrackPoints (frame_to_frame_..._single_thread.cpp:11-82).
- * The per-id transform map of the reference holds translation = float(position) for every id of the
- * database (its linear part is reset to identity at the start of each TrackPoint and never read). */
+ * transform_ holds one AffineCompact2f per id.  Its linear part is reset to identity at the start of
+ * each TrackPoint (:93) and never read.  Its translation is float(position) when the id enters the
+ * map (:61-66 first call, :73-80 later) and is NOT refreshed from the database afterwards: an id that
+ * survived the previous Track is tracked from the translation stored then, even if the caller has
+ * rewritten its position since (FeatureDetectorShiTomasiBucketing does, to the feature whose id
+ * equals its counter, Q6).  Ids absent from the database are erased (:82-90), so after each call the
+ * map is the database (ids, float positions). */
 int orc_lssd_tracker_track(orc_lssd_tracker* t, const uint8_t* cur, int w, int h, int stride,
                            uint64_t* ids, double* xy, uint32_t* age, int* n_inout) {
   orc_pyramid16 pyr;
   if (orc_lssd_build_pyramid(cur, w, h, stride, t->optical_flow_levels, &pyr)) return -1;
+  const int n0 = *n_inout;
   if (!t->has_old) { /* :57-68 */
     t->old_pyr = pyr;
     t->has_old = 1;
+    lssd_map_store(t, ids, xy, n0);
     return 0;
   }
-  const int n0 = *n_inout;
   int n = 0;
   for (int i = 0; i < n0; i++) {
-    const float p1[2] = {(float)xy[2 * i], (float)xy[2 * i + 1]};
+    float p1[2] = {(float)xy[2 * i], (float)xy[2 * i + 1]}; /* :73-80 new to the map */
+    for (int j = 0; j < t->map_n; j++)
+      if (t->map_ids[j] == ids[i]) { /* already in the map: stored translation */
+        p1[0] = t->map_xy[2 * j];
+        p1[1] = t->map_xy[2 * j + 1];
+        break;
+      }
     float p2[2] = {p1[0], p1[1]};
     int valid = orc_lssd_track_point(&t->old_pyr, &pyr, p1, p2, t->optical_flow_levels,
                                      t->optical_flow_max_iterations, t->mode);
@@ -1447,6 +1479,7 @@ int orc_lssd_tracker_track(orc_lssd_tracker* t, const uint8_t* cur, int w, int h
     }
   }
   *n_inout = n;
+  lssd_map_store(t, ids, xy, n); /* :102 transform_ = new_transform */
   orc_lssd_free_pyramid(&t->old_pyr);
   t->old_pyr = pyr;
   return 0;

@@ -193,6 +193,10 @@ typedef struct {
   int mode;
   orc_pyramid16 old_pyr;
   int has_old;
+  /* transform_ (FeatureTrackerLSSDLucasKanade.hpp:51): id -> float translation, kept between calls */
+  uint64_t* map_ids;
+  float* map_xy;
+  int map_n, map_cap;
 } orc_lssd_tracker;
 
 void orc_lssd_tracker_init(orc_lssd_tracker* t, double max_recovered_dist, int32_t levels,

@@ -5,6 +5,8 @@
 //   usage: frontend_mirror_main frames.raw W H N out.txt rows cols maxN minDist iter eps win lvl back
 // rows == 0 selects FeatureDetectorANMS (Parameter defaults with max_feature_number_ = maxN,
 // min_feature_distance_ = minDist, detection_feature_number_ = 2 * maxN) instead of the bucketing detector.
+// iter == 0 selects FeatureTrackerLSSDLucasKanade (Parameter defaults) driven the way
+// KimeraFrontend.cpp drives a tracker: the 3-argument Track on every frame, then the detector.
 #include <cstdio>
 #include <cstdlib>
 #include <functional>
@@ -42,14 +44,19 @@ int main(int argc, char** argv) {
       max_index = [d]() { return d->max_feature_index(); };
     }
     vslam::feature::FeatureDetectorBase& shi_tomasi_detector = *detector_ptr;
-    vslam::feature::FeatureTrackerLucasKanade kl_tracker(std::atoi(argv[10]), std::atof(argv[11]), std::atoi(argv[12]),
-                                                         std::atoi(argv[13]), std::atof(argv[14]));
+    const bool use_lssd = std::atoi(argv[10]) == 0;
+    vslam::feature::FeatureTrackerLucasKanade kl_tracker(use_lssd ? 30 : std::atoi(argv[10]), std::atof(argv[11]),
+                                                         std::atoi(argv[12]), std::atoi(argv[13]), std::atof(argv[14]));
+    vslam::feature::FeatureTrackerLSSDLucasKanade lssd_tracker{vslam::feature::FeatureTrackerLSSDLucasKanade::Parameter()};
     vslam::FeaturePositionDatabase prev_feature_position;
     vslam::FeatureAgeDatabase prev_feature_age;
     FILE* out = std::fopen(argv[5], "w");
     for (int k = 0; k < N; k++) {
       vslam::feature::ImageView frame(buf.data() + (size_t)k * W * H, W, H);
-      if (k == 0) {
+      if (use_lssd) {
+        lssd_tracker.Track(prev_feature_position, prev_feature_age, frame);
+        if (k % 2 == 0) shi_tomasi_detector.UpdateDetection(prev_feature_position, prev_feature_age, frame);
+      } else if (k == 0) {
         shi_tomasi_detector.UpdateDetection(prev_feature_position, prev_feature_age, frame);
       } else {
         if (k % 2 == 0) shi_tomasi_detector.UpdateDetection(prev_feature_position, prev_feature_age, frame);

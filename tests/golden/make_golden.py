@@ -92,6 +92,30 @@ def run_case(w, h, seed, n_frames, det_args, trk_args):
         out["anms_det%d_maxidx" % k] = np.array([det.max_feature_index], np.uint64)
     out["anms_kp0"] = O.good_features_to_track(frames[0], 2 * amax, 0.001, 1.0,
                                                mask=det.build_mask(w, h, np.zeros((0, 2))), block_size=4)
+    # the LSSD SE(2) patch tracker (FeatureTrackerLSSDLucasKanade, default Parameter): pyramid, point
+    # tracking in both summation orders, and the frontend sequence with the bucketing detector
+    lp = O.lssd_build_pyramid(frames[0], 3)
+    for l in range(1, 4):
+        out["lssd_pyr%d" % l] = lp[l]
+    kp = O.good_features_to_track(frames[0], 60, 0.01, 5.0)
+    lpts = np.concatenate([kp + 0.25, pts[:20]]).astype(np.float32)
+    out["lssd_pts"] = lpts
+    for mode, tag in ((O.LSSD_SEQ, "seq"), (O.LSSD_TREE, "tree")):
+        nxt, ok = O.lssd_track_points(frames[0], frames[1], lpts, 3, 5, mode)
+        out["lssd_next_" + tag], out["lssd_valid_" + tag] = nxt, ok
+    det = O.Detector(*det_args)
+    trk = O.LssdTracker(mode=O.LSSD_TREE)
+    tab = O.FeatureTable(CAP)
+    for k in range(n_frames):
+        assert trk.track(tab, frames[k]) == 0
+        n = tab.n.value
+        out["lssd_trk%d_ids" % k] = tab.ids[:n].copy()
+        out["lssd_trk%d_xy" % k] = tab.xy[:n].copy()
+        assert det.update_detection(tab, frames[k]) == 0
+        n = tab.n.value
+        out["lssd_det%d_ids" % k] = tab.ids[:n].copy()
+        out["lssd_det%d_xy" % k] = tab.xy[:n].copy()
+        out["lssd_det%d_age" % k] = tab.age[:n].copy()
     return out
 
 

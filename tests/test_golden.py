@@ -81,3 +81,28 @@ def test_oracle_anms_matches_golden(oracle, path):
 
 def test_golden_fixtures_exist():
     assert len(GOLD) >= 3
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_oracle_lssd_matches_golden(oracle, path):
+    g = np.load(path)
+    frames = g["frames"]
+    d = tuple(g["det_args"])
+    det_args = (int(d[0]), int(d[1]), int(d[2]), float(d[3]))
+    lp = oracle.lssd_build_pyramid(frames[0], 3)
+    for l in range(1, 4):
+        assert np.array_equal(lp[l], g["lssd_pyr%d" % l])
+    for mode, tag in ((oracle.LSSD_SEQ, "seq"), (oracle.LSSD_TREE, "tree")):
+        nxt, ok = oracle.lssd_track_points(frames[0], frames[1], g["lssd_pts"], 3, 5, mode)
+        assert np.array_equal(ok, g["lssd_valid_" + tag])
+        v = ok.astype(bool)
+        assert np.array_equal(_u32(nxt[v]), _u32(g["lssd_next_" + tag][v]))
+    det, trk, tab = oracle.Detector(*det_args), oracle.LssdTracker(mode=oracle.LSSD_TREE), oracle.FeatureTable(CAP)
+    for k in range(len(frames)):
+        assert trk.track(tab, frames[k]) == 0
+        n = tab.n.value
+        assert np.array_equal(tab.ids[:n], g["lssd_trk%d_ids" % k]) and np.array_equal(tab.xy[:n], g["lssd_trk%d_xy" % k])
+        assert det.update_detection(tab, frames[k]) == 0
+        n = tab.n.value
+        assert np.array_equal(tab.ids[:n], g["lssd_det%d_ids" % k]) and np.array_equal(tab.xy[:n], g["lssd_det%d_xy" % k])
+        assert np.array_equal(tab.age[:n], g["lssd_det%d_age" % k])

@@ -43,3 +43,33 @@ def test_cpp_mirror_matches_oracle(oracle, synth, tmp_path, det_args):
         assert got[k]["tab"] == tab.as_dict(), "frame %d" % k
         assert got[k]["maxidx"] == det.max_feature_index
     assert len(got[-1]["tab"]) > 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("det_args", [(3, 3, 180, 5.0), (0, 0, 120, 9.0)])
+def test_cpp_mirror_lssd_tracker_matches_oracle(oracle, synth, tmp_path, det_args):
+    """FeatureTrackerLSSDLucasKanade through the C++ mirror (unordered databases: the table order
+    changes between calls, the tracker's per-id state is matched by id)."""
+    w, h, n = 400, 300, 6
+    frames, _ = synth.sequence(78, w, h, n)
+    raw, out = str(tmp_path / "f.raw"), str(tmp_path / "o.txt")
+    frames.tofile(raw)
+    subprocess.check_call([EXE, raw, str(w), str(h), str(n), out] + [str(v) for v in det_args + (0, 0, 0, 0, 0)],
+                          timeout=120)
+    got, cur = [], None
+    for line in open(out):
+        p = line.split()
+        if p[0] == "frame":
+            cur = {"maxidx": int(p[3]), "tab": {}}
+            got.append(cur)
+        else:
+            cur["tab"][int(p[0])] = (float(p[1]), float(p[2]), int(p[3]))
+    det = oracle.Detector(*det_args) if det_args[0] else oracle.AnmsDetector(det_args[2], det_args[3])
+    trk, tab = oracle.LssdTracker(mode=oracle.LSSD_TREE), oracle.FeatureTable(1024)
+    for k in range(n):
+        trk.track(tab, frames[k])
+        if k % 2 == 0:
+            det.update_detection(tab, frames[k])
+        assert got[k]["tab"] == tab.as_dict(), "frame %d" % k
+        assert got[k]["maxidx"] == det.max_feature_index
+    assert len(got[-1]["tab"]) > 20

@@ -104,6 +104,38 @@ def test_batch_matches_per_stream_oracle(vsf, oracle, synth):
     ctx.close()
 
 
+def test_caller_rewrites_table_between_calls(vsf, oracle, synth):
+    """The tracker's own id -> translation map (transform_): rewritten positions of surviving ids are
+    ignored, new ids start from the table, and a reordered table is matched by id."""
+    w, h = 320, 240
+    frames, _ = synth.sequence(12, w, h, 4)
+    kp = oracle.good_features_to_track(frames[0], 90, 0.01, 8.0).astype(np.float64)
+    n = len(kp)
+    ctx = vsf.Context(_params(vsf, w, h, capacity=128))
+    ids, xy, age = np.zeros(128, np.uint64), np.zeros((128, 2)), np.zeros(128, np.uint32)
+    ids[:n], xy[:n], age[:n] = np.arange(1, n + 1), kp, 1
+    T = oracle.FeatureTable(128)
+    T.set(ids[:n].copy(), kp.copy(), age[:n].copy())
+    ot = oracle.LssdTracker(mode=oracle.LSSD_TREE)
+    rng = np.random.default_rng(0)
+    for t, fr in enumerate(frames):
+        n, _ = ctx.track(fr, ids, xy, age, n)
+        ot.track(T, fr)
+        assert n == T.n.value and n > 5
+        assert np.array_equal(ids[:n], T.ids[:n]) and np.array_equal(xy[:n], T.xy[:n])
+        # reorder the table, rewrite two positions, rename one id, append a new feature
+        perm = rng.permutation(n)
+        ids[:n], xy[:n], age[:n] = ids[perm], xy[perm], age[perm]
+        xy[0] = [40.0 + t, 50.0]
+        xy[3] += 2.5
+        ids[5] = 1000 + t
+        for k in range(20):
+            ids[n], xy[n], age[n] = 2000 + 100 * t + k, kp[(7 * t + k) % len(kp)] + 0.5, 1
+            n += 1
+        T.set(ids[:n].copy(), xy[:n].copy(), age[:n].copy())
+    ctx.close()
+
+
 def test_errors_and_edges(vsf, oracle, synth):
     w, h = 160, 120
     with pytest.raises(vsf.VsfError):
@@ -138,3 +170,36 @@ def test_errors_and_edges(vsf, oracle, synth):
         lk.debug_lssd(frames[0], frames[1], np.zeros((2, 2), np.float32))
     lk.close()
     ctx.close()
+
+
+import glob  # noqa: E402
+import os  # noqa: E402
+
+GOLD = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+
+
+@pytest.mark.parametrize("path", GOLD, ids=[os.path.basename(p) for p in GOLD])
+def test_golden_on_gpu(vsf, path):
+    """The committed fixtures (tests/golden/make_golden.py) against the HIP path; no oracle involved."""
+    g = np.load(path)
+    frames = g["frames"]
+    h, w = frames[0].shape
+    d = g["det_args"]
+    ctx = vsf.Context(_params(vsf, w, h))
+    got = ctx.debug_lssd_pyramid(frames[0])
+    for l in range(1, 4):
+        assert np.array_equal(got[l - 1], g["lssd_pyr%d" % l])
+    nxt, ok = ctx.debug_lssd(frames[0], frames[1], g["lssd_pts"])
+    assert np.array_equal(ok, g["lssd_valid_tree"])
+    v = ok.astype(bool)
+    assert np.array_equal(nxt[v], g["lssd_next_tree"][v])
+    ctx.close()
+    trk = vsf.FeatureTrackerLSSDLucasKanade(vsf.FeatureTrackerLSSDLucasKanade.Parameter(), w, h, capacity=256)
+    det = vsf.FeatureDetectorShiTomasiBucketing(int(d[0]), int(d[1]), int(d[2]), float(d[3]), w, h, capacity=256)
+    db = vsf.FeatureDatabase(256)
+    for k in range(len(frames)):
+        trk.Track(db, frames[k])
+        assert np.array_equal(db.ids[:db.n], g["lssd_trk%d_ids" % k]) and np.array_equal(db.xy[:db.n], g["lssd_trk%d_xy" % k])
+        det.UpdateDetection(db, frames[k])
+        assert np.array_equal(db.ids[:db.n], g["lssd_det%d_ids" % k]) and np.array_equal(db.xy[:db.n], g["lssd_det%d_xy" % k])
+        assert np.array_equal(db.age[:db.n], g["lssd_det%d_age" % k])

@@ -105,3 +105,41 @@ def test_tracker_semantics(oracle, synth):
     # empty table
     T3 = oracle.FeatureTable(4)
     assert trk.track(T3, frames[2]) == 0 and T3.n.value == 0
+
+
+def test_tracker_keeps_its_own_translation_per_id(oracle, synth):
+    """transform_ is refreshed from the database only for ids new to it (:73-80): a position the caller
+    rewrites for a surviving id is ignored, a new id starts from the table."""
+    w, h = 320, 240
+    frames, _ = synth.sequence(12, w, h, 3)
+    kp = oracle.good_features_to_track(frames[0], 60, 0.01, 10.0).astype(np.float64)
+    n0 = len(kp)
+    ids = np.arange(1, n0 + 1, dtype=np.uint64)
+
+    def run(mutate):
+        T = oracle.FeatureTable(128)
+        T.set(ids.copy(), kp.copy(), np.ones(n0, np.uint32))
+        trk = oracle.LssdTracker()
+        trk.track(T, frames[0])
+        trk.track(T, frames[1])
+        mutate(T)
+        trk.track(T, frames[2])
+        return T.as_dict()
+
+    base = run(lambda T: None)
+
+    def rewrite(T):  # same id, another position: ignored
+        T.xy[0] = [17.0, 23.0]
+
+    seen = {}
+
+    def rename(T):   # a new id at another tracked position: starts from the table
+        seen["a"], seen["b"] = int(T.ids[0]), int(T.ids[1])
+        T.ids[0] = 999
+        T.xy[0] = T.xy[1]
+
+    assert run(rewrite) == base
+    got = run(rename)
+    assert seen["a"] not in got
+    if seen["b"] in got:
+        assert got[999][:2] == got[seen["b"]][:2]

@@ -98,6 +98,9 @@ struct vsf_ctx {
   int l16w[LSSD_MAXL] = {}, l16h[LSSD_MAXL] = {};
   uint16_t* lssd_pyr[2][LSSD_MAXL] = {};
   uint16_t* lssd_pair_pyr[2][LSSD_MAXL] = {};  // single-stream debug pair, allocated lazily
+  uint64_t* d_lssd_ids = nullptr;  // the tracker's own id -> translation map (see LssdState)
+  float2* d_lssd_xy = nullptr;
+  int* d_lssd_n = nullptr;
   // frontend step (allocated on first use)
   double* d_fe_dt = nullptr;
   int* d_fe_kf = nullptr;
@@ -311,12 +314,20 @@ int lssd_track_impl(vsf_ctx* c, const FrameRef& f, int streams, hipStream_t s) {
       int fgrid = (c->p.max_features + 64 + 1) / 2;  // feature pairs per stream
       if (fgrid > (c->cap + 1) / 2) fgrid = (c->cap + 1) / 2;
       dim3 grid((unsigned)(8 * fgrid * ((streams + 7) / 8)));
-      hipLaunchKernelGGL(lssd_fb_kernel, grid, dim3(64), 0, s, P, C, c->d_xy, c->d_n, c->cap, fgrid, streams, c->lssd,
-                         c->d_fwd, c->d_flags);
+      const LssdState st = {c->d_lssd_ids, c->d_lssd_xy, c->d_lssd_n};
+      hipLaunchKernelGGL(lssd_fb_kernel, grid, dim3(64), 0, s, P, C, c->d_ids, c->d_xy, c->d_n, c->cap, fgrid, streams,
+                         c->lssd, st, c->d_fwd, c->d_flags);
       HIPCHK(c, hipGetLastError());
     }
     rc = launch_compact(c, streams, s);
     if (rc) return rc;
+  }
+  {
+    int gx = (c->p.max_features + 64 + 255) / 256;
+    if (gx > (c->cap + 255) / 256) gx = (c->cap + 255) / 256;
+    hipLaunchKernelGGL(lssd_snapshot_kernel, dim3(gx, streams), dim3(256), 0, s, c->d_ids, c->d_xy, c->d_n, c->cap,
+                       c->d_lssd_ids, c->d_lssd_xy, c->d_lssd_n);
+    HIPCHK(c, hipGetLastError());
   }
   c->cur = nxt;
   c->has_prev = true;
@@ -585,6 +596,9 @@ void vsf_destroy(vsf_ctx* c) {
     if (c->own_frame[i]) (void)hipFree(c->own_frame[i]);
     if (c->pair_frame[i]) (void)hipFree(c->pair_frame[i]);
   }
+  void* lssd_bufs[] = {c->d_lssd_ids, c->d_lssd_xy, c->d_lssd_n};
+  for (void* b : lssd_bufs)
+    if (b) (void)hipFree(b);
   void* bufs[] = {c->det_frame, c->det_mask, c->d_ids,    c->d_xy,      c->d_age,   c->d_n,      c->d_fwd,
                   c->d_flags,   c->d_stats,  c->d_status, c->d_maxidx,  c->d_rects, c->d_origin, c->d_lam_off,
                   c->d_need,    c->d_nact,   c->d_cellmax, c->d_candcnt, c->d_cand,  c->d_lam,    c->d_selxy,
@@ -805,9 +819,14 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   A(dalloc(c, &c->d_lam, (size_t)B * c->lam_total));
   A(dalloc(c, &c->d_selxy, BC * (size_t)(c->grid_max > 0 ? c->grid_max : 1)));
   A(dalloc(c, &c->d_selcnt, BC));
-  if (use_lssd)
+  if (use_lssd) {
+    A(dalloc(c, &c->d_lssd_ids, (size_t)B * c->cap));
+    A(dalloc(c, &c->d_lssd_xy, (size_t)B * c->cap));
+    A(dalloc(c, &c->d_lssd_n, (size_t)B));
+    if (!rc && hipMemset(c->d_lssd_n, 0, sizeof(int) * (size_t)B) != hipSuccess) rc = VSF_E_HIP;
     for (int i = 0; i < 2; i++)
       for (int l = 1; l <= p->lssd_levels; l++) A(dalloc(c, &c->lssd_pyr[i][l], (size_t)B * c->l16w[l] * c->l16h[l] + 8));
+  }
   if (use_anms) {
     A(dalloc(c, &c->d_aflag, (size_t)B * fs));
     A(dalloc(c, &c->d_arect, (size_t)1));

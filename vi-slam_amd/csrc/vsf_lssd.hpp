@@ -356,23 +356,54 @@ __device__ bool lssd_track_point(const Pyr16View& OLD, const Pyr16View& CUR, int
   return valid;
 }
 
+// The reference tracker keeps its own id -> transform map between calls
+// (FeatureTrackerLSSDLucasKanade.cpp:70-91): an id that was in the map after the previous Track keeps
+// the float translation stored there, whatever the caller's table says now (the bucketing detector
+// overwrites the position of the feature whose id equals its counter, Q6); only ids new to the map
+// start from the table position.  The map after a Track is the table after that Track, so the state
+// is a snapshot of (id, float xy) per stream.
+struct LssdState {
+  const uint64_t* ids;  // [streams][cap]
+  const float2* xy;     // [streams][cap]
+  const int* n;         // [streams]
+};
+
 // flags as lk_fb_kernel: bit0 forward valid, bit1 backward valid, bit2 kept.  Two features per wave.
-__global__ __launch_bounds__(64) void lssd_fb_kernel(Pyr16View P, Pyr16View C, const double2* __restrict__ xy,
-                                                     const int* __restrict__ n, int cap, int fgrid, int nstreams,
-                                                     LssdParams prm, float2* __restrict__ fwd,
-                                                     uint8_t* __restrict__ flags) {
+__global__ __launch_bounds__(64) void lssd_fb_kernel(Pyr16View P, Pyr16View C, const uint64_t* __restrict__ ids,
+                                                     const double2* __restrict__ xy, const int* __restrict__ n,
+                                                     int cap, int fgrid, int nstreams, LssdParams prm, LssdState st,
+                                                     float2* __restrict__ fwd, uint8_t* __restrict__ flags) {
   const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;  // same XCD-aware map as lk_fb_kernel
   const int grp = local / fgrid;
   const int stream = grp * 8 + xcd, pair0 = local - grp * fgrid;
   if (stream >= nstreams) return;
   const int nf = n[stream];
-  const int half = (threadIdx.x >> 5) & 1;
+  const int half = (threadIdx.x >> 5) & 1, sub = threadIdx.x & 31;
+  const long long sb = (long long)stream * cap;
+  const int st_n = st.n[stream];
   for (int f0 = 2 * pair0; f0 < nf; f0 += 2 * fgrid) {
     const int f = f0 + half;
     const bool active = f < nf;
     double2 p0 = make_double2(0.0, 0.0);
-    if (active) p0 = xy[(long long)stream * cap + f];
-    const float p1x = (float)p0.x, p1y = (float)p0.y;  // transform.translation() = pos.cast<float>() (:64,:77)
+    int hit = -1;
+    if (active) {
+      p0 = xy[sb + f];
+      const uint64_t id = ids[sb + f];
+      if (f < st_n && st.ids[sb + f] == id) {
+        hit = f;  // the usual case: survivors keep their slots, the detector appends behind them
+      } else {
+        for (int j = sub; j < st_n; j += 32)
+          if (st.ids[sb + j] == id) hit = j;
+      }
+    }
+#pragma unroll
+    for (int step = 1; step < 32; step <<= 1) hit = max(hit, __shfl_xor(hit, step, 32));
+    float p1x = (float)p0.x, p1y = (float)p0.y;  // transform.translation() = pos.cast<float>() (:64,:77)
+    if (hit >= 0) {
+      const float2 q = st.xy[sb + hit];
+      p1x = q.x;
+      p1y = q.y;
+    }
     float qx = p1x, qy = p1y;
     uint8_t flag = 0;
     const bool v1 = lssd_track_point(P, C, stream, active, p1x, p1y, qx, qy, prm);
@@ -385,11 +416,26 @@ __global__ __launch_bounds__(64) void lssd_fb_kernel(Pyr16View P, Pyr16View C, c
       const float dist2 = ddx * ddx + ddy * ddy;
       if ((double)dist2 < prm.max_recovered_dist) flag |= 4;  // :67
     }
-    if (active && (threadIdx.x & 31) == 0) {
-      fwd[(long long)stream * cap + f] = make_float2(qx, qy);
-      flags[(long long)stream * cap + f] = flag;
+    if (active && sub == 0) {
+      fwd[sb + f] = make_float2(qx, qy);
+      flags[sb + f] = flag;
     }
   }
+}
+
+// state <- table (after the first call's early return :57-68, and after every later Track :102)
+__global__ void lssd_snapshot_kernel(const uint64_t* __restrict__ ids, const double2* __restrict__ xy,
+                                     const int* __restrict__ n, int cap, uint64_t* __restrict__ st_ids,
+                                     float2* __restrict__ st_xy, int* __restrict__ st_n) {
+  const int stream = blockIdx.y;
+  const int nf = n[stream];
+  const long long sb = (long long)stream * cap;
+  for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < nf; f += gridDim.x * blockDim.x) {
+    const double2 p = xy[sb + f];
+    st_ids[sb + f] = ids[sb + f];
+    st_xy[sb + f] = make_float2((float)p.x, (float)p.y);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) st_n[stream] = nf;
 }
 
 // TrackPoint (forward only) on a point list, for parity tests

@@ -364,5 +364,82 @@ class FeatureTrackerLucasKanade : public FeatureTrackerBase {
   vsf_track_stats stats_{};
 };
 
+// ref: FeatureTrackerLSSDLucasKanade.hpp:17-54 -- Parameter by its reference field names, the
+// stateful 3-argument Track only (the class has no frame-pair form).
+class FeatureTrackerLSSDLucasKanade : public FeatureTrackerBase {
+ public:
+  class Parameter {
+   public:
+    Parameter()  // FeatureTrackerLSSDLucasKanade.cpp:13-23
+        : optical_flow_type_("frame_to_frame"),
+          optical_flow_detection_grid_size_(32),
+          optical_flow_max_recovered_dist_(0.09),
+          optical_flow_pattern_(51),
+          optical_flow_max_iterations_(5),
+          optical_flow_levels_(3) {}
+    std::string optical_flow_type_;
+    int optical_flow_detection_grid_size_;
+    double optical_flow_max_recovered_dist_;
+    int optical_flow_pattern_;  // not read: the frame-to-frame class fixes Pattern24
+    int optical_flow_max_iterations_;
+    int optical_flow_levels_;
+  };
+
+  explicit FeatureTrackerLSSDLucasKanade(const Parameter& parameter, int device_id = 0)
+      : parameter_(parameter), device_id_(device_id) {}
+
+  void Track(FeaturePositionDatabase& feature_position, FeatureAgeDatabase& feature_age,
+             const ImageView& current_frame) override {
+    ensure(current_frame.cols, current_frame.rows, feature_position.size() + 64);
+    std::vector<uint64_t> ids;
+    std::vector<double> xy;
+    std::vector<uint32_t> ag;
+    detail::flatten(feature_position, feature_age, capacity_, ids, xy, ag);
+    int32_t n = (int32_t)feature_position.size();
+    const bool first = !has_prev_;
+    detail::check(ctx_.get(),
+                  vsf_track(ctx_.get(), current_frame.data, current_frame.cols, current_frame.rows,
+                            current_frame.step, ids.data(), xy.data(), ag.data(), &n, &stats_),
+                  "Track");
+    has_prev_ = true;
+    if (first) return;  // ref :57-68: pyramid and transforms stored, databases untouched
+    detail::unflatten(ids, xy, ag, n, feature_position, feature_age);  // ref :105-113
+  }
+
+  const vsf_track_stats& last_stats() const { return stats_; }
+
+ private:
+  void ensure(int w, int h, size_t need) {
+    if (ctx_ && w == w_ && h == h_ && need <= capacity_) return;
+    if (ctx_ && w == w_ && h == h_ && has_prev_)
+      throw std::runtime_error("vsf: feature table grew beyond the tracker capacity between frames");
+    has_prev_ = false;
+    vsf_params p;
+    vsf_default_params(&p);
+    p.tracker_kind = VSF_TRACKER_LSSD;
+    p.lssd_levels = parameter_.optical_flow_levels_;
+    p.lssd_max_iterations = parameter_.optical_flow_max_iterations_;
+    p.lssd_max_recovered_dist = parameter_.optical_flow_max_recovered_dist_;
+    p.width = w;
+    p.height = h;
+    p.device_id = device_id_;
+    p.capacity = (int32_t)(need < 4096 ? 4096 : need * 2);
+    vsf_ctx* c = nullptr;
+    detail::check(nullptr, vsf_create(&p, &c), "vsf_create(lssd tracker)");
+    ctx_.reset(c);
+    w_ = w;
+    h_ = h;
+    capacity_ = (size_t)p.capacity;
+  }
+
+  Parameter parameter_;
+  int device_id_;
+  detail::CtxPtr ctx_;
+  int w_ = 0, h_ = 0;
+  size_t capacity_ = 0;
+  bool has_prev_ = false;
+  vsf_track_stats stats_{};
+};
+
 }  // namespace feature
 }  // namespace vslam
