@@ -101,6 +101,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--detector", choices=("bucketing", "anms"), default="bucketing",
                     help="FeatureDetectorShiTomasiBucketing (the headline configuration) or FeatureDetectorANMS")
+    ap.add_argument("--tracker", choices=("lk", "lssd"), default="lk",
+                    help="FeatureTrackerLucasKanade (the headline configuration) or FeatureTrackerLSSDLucasKanade")
     ap.add_argument("--cpu-streams", type=int, default=64)
     ap.add_argument("--cpu-steps", type=int, default=100)
     args = ap.parse_args()
@@ -131,7 +133,8 @@ def main():
                            min_distance=MIN_DIST, klt_win=WIN, klt_max_level=LEVELS - 1, klt_max_iter=30,
                            klt_eps=0.01, backtrack_thr=1.0, width=W, height=H, streams=B,
                            device_id=local_rank,
-                           detector_kind=vsf.DETECTOR_ANMS if args.detector == "anms" else vsf.DETECTOR_BUCKETING)
+                           detector_kind=vsf.DETECTOR_ANMS if args.detector == "anms" else vsf.DETECTOR_BUCKETING,
+                           tracker_kind=vsf.TRACKER_LSSD if args.tracker == "lssd" else vsf.TRACKER_LK)
     ctx = vsf.Context(p)
     cap = ctx.capacity
     stream = torch.cuda.current_stream().cuda_stream
@@ -185,12 +188,20 @@ def main():
         P1 = P - W * H
         alg_step = 2 * W * H + P1 + 2 * P + 24 * MAX_FEATURES  # 1,806,360 B at C2
         alg_lk = 2 * P + 24 * MAX_FEATURES                     # the LK kernel's share per frame
+        kernel_name = "lk_fb_kernel"
+        if args.tracker == "lssd":  # two u8 frames + two sets of u16 levels 1..3 + the table
+            p16 = sum(2 * (W >> l) * (H >> l) for l in range(1, 4))
+            alg_lk = 2 * (W * H + p16) + 24 * MAX_FEATURES
+            alg_step = 2 * W * H + W * H + p16 + alg_lk
+            kernel_name = "lssd_fb_kernel"
         lk_ms, lk_n = prof["lk"]
         lk_avg = (lk_ms / lk_n) * 1e-3 if lk_n else float("nan")
         achieved = alg_lk * B / lk_avg / 1e9 if lk_n else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "lk_traffic.json")
-        if os.path.exists(tpath):
+        tpath = None
+        if args.tracker == "lk":
+            tpath = os.path.join(ROOT, "profiles", "lk_traffic.json")
+        if tpath and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 if tj.get("streams") == B:
@@ -198,7 +209,8 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "frames/s detect+KLT-track @752x480",
+            "metric": "frames/s detect+KLT-track @752x480" if args.tracker == "lk"
+                      else "frames/s detect+LSSD-track @752x480",
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -210,18 +222,20 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/i32 (f32 2x2 solve)",
             "data": "synthetic",
-            "config": {"workload": "C2: synthetic 752x480 8-bit frames, 4-level pyramid, 21x21 LK window, "
+            "config": {"workload": "C2: synthetic 752x480 8-bit frames, %s, "
                                    "%s / 300 features, %d streams per GPU resident in HBM"
-                                   % ("4x4 grid" if args.detector == "bucketing" else "ANMS detector", B),
+                                   % ("4-level pyramid, 21x21 LK window" if args.tracker == "lk"
+                                      else "LSSD SE(2) tracker (Pattern24, 3+1 u16 levels, 5 iterations)",
+                                      "4x4 grid" if args.detector == "bucketing" else "ANMS detector", B),
                        "streams_per_gpu": B, "frames_per_step": world * B,
                        "mean_features_per_stream": mean_feats, "verified_fraction": kept_frac},
-            "roofline": {"bound": "hbm", "kernel": "lk_fb_kernel", "achieved": achieved, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
                          "avg_launch_ms": lk_avg * 1e3, "algorithmic_bytes_per_launch": alg_lk * B},
             "step_hbm_frac": alg_step * value / world / HBM_PEAK,
             "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()},
         }
-        if not args.no_cpu and args.detector == "bucketing":
+        if not args.no_cpu and args.detector == "bucketing" and args.tracker == "lk":
             line["cpu_baseline"] = cpu_baseline(frames, order, args)
         print(json.dumps(line))
     if dist is not None:
