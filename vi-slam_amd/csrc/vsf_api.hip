@@ -273,7 +273,7 @@ int lssd_build_pyramid(vsf_ctx* c, const FrameRef& f, uint16_t* const* lv, int s
   for (int l = 1; l <= c->lssd.levels; l++) {
     const int dw = c->l16w[l], dh = c->l16h[l];
     if (dw <= 0 || dh <= 0) continue;
-    dim3 grid((dw + 63) / 64, (dh + 3) / 4, streams);
+    dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, streams);
     if (l == 1)
       hipLaunchKernelGGL(lssd_subsample_kernel<true>, grid, dim3(256), 0, s, f.ptr, f.sstride, f.pitch, c->l16w[0],
                          c->l16h[0], lv[1], dw, dh);

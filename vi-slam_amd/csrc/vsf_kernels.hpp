@@ -14,6 +14,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 #ifndef VSF_LK_WAVES
 #define VSF_LK_WAVES 5  // waves per SIMD the LK kernels are register-limited to (window <= 21)

@@ -39,32 +39,41 @@ struct LssdParams {
 
 // basalt::ManagedImagePyr<uint16_t>::subsample: [1 4 6 4 1]^2 in int, REFLECT_101, (v + 128) >> 8, size (w/2, h/2).
 // SRC8: source is the u8 frame read as v << 8.
+// 64x16 output tile per block: the 131x35 source tile is staged in LDS, filtered along x into u32, then along y
+// (integer arithmetic, so the order of the two passes does not change the result).
 template <bool SRC8>
 __global__ __launch_bounds__(256) void lssd_subsample_kernel(const void* __restrict__ src, long long src_sstride,
                                                              int src_pitch, int sw, int sh,
                                                              uint16_t* __restrict__ dst, int dw, int dh) {
-  const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  using src_t = typename std::conditional<SRC8, uint8_t, uint16_t>::type;
+  __shared__ src_t s_src[PD_SH * PD_SP];
+  __shared__ uint32_t s_h[PD_SH * PD_TW];
   const int stream = blockIdx.z;
-  if (x >= dw || y >= dh) return;
-  const int k[5] = {1, 4, 6, 4, 1};
-  int acc = 0;
-#pragma unroll
-  for (int j = -2; j <= 2; j++) {
-    const int yy = reflect101(2 * y + j, sh);
-    int r = 0;
-#pragma unroll
-    for (int i = -2; i <= 2; i++) {
-      const int xx = reflect101(2 * x + i, sw);
-      int v;
-      if (SRC8)
-        v = (int)(reinterpret_cast<const uint8_t*>(src) + (long long)stream * src_sstride)[(long long)yy * src_pitch + xx] << 8;
-      else
-        v = (int)(reinterpret_cast<const uint16_t*>(src) + (long long)stream * src_sstride)[(long long)yy * src_pitch + xx];
-      r += k[i + 2] * v;
-    }
-    acc += k[j + 2] * r;
+  const src_t* S = reinterpret_cast<const src_t*>(src) + (long long)stream * src_sstride;
+  const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
+  const int sx0 = 2 * ox - 2, sy0 = 2 * oy - 2;
+  for (int i = threadIdx.x; i < PD_SH * PD_SW; i += 256) {
+    const int y = i / PD_SW, x = i - y * PD_SW;
+    const int gy = reflect101(sy0 + y, sh), gx = reflect101(sx0 + x, sw);
+    s_src[y * PD_SP + x] = S[(long long)gy * src_pitch + gx];
   }
-  dst[((long long)stream * dh + y) * dw + x] = (uint16_t)((acc + (1 << 7)) >> 8);
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD_SH * PD_TW; i += 256) {
+    const int y = i / PD_TW, x = i - y * PD_TW;
+    const src_t* r = s_src + y * PD_SP + 2 * x;
+    const uint32_t v = (uint32_t)r[0] + 4u * r[1] + 6u * r[2] + 4u * r[3] + r[4];
+    s_h[i] = SRC8 ? (v << 8) : v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < PD_TH * PD_TW; i += 256) {
+    const int y = i / PD_TW, x = i - y * PD_TW;
+    const int gx = ox + x, gy = oy + y;
+    if (gx < dw && gy < dh) {
+      const uint32_t* c = s_h + (2 * y) * PD_TW + x;
+      const uint32_t v = c[0] + 4u * c[PD_TW] + 6u * c[2 * PD_TW] + 4u * c[3 * PD_TW] + c[4 * PD_TW];
+      dst[((long long)stream * dh + gy) * dw + gx] = (uint16_t)((v + 128u) >> 8);
+    }
+  }
 }
 
 struct Lvl16 {  // one level of one stream
