@@ -133,10 +133,23 @@ __device__ __forceinline__ void lssd_interp_grad(const Lvl16& im, float x, float
 }
 
 // 32-slot butterfly sum: every lane of the half-wavefront ends with the same value
+// Butterfly sum over a 32-lane half, every lane of the half gets the total.  The partner of step k is lane i ^ k;
+// after the steps 1 and 2 a quad is uniform, so lane i ^ 7 (row_half_mirror) holds what lane i ^ 4 holds, and
+// lane i ^ 15 (row_mirror) what lane i ^ 8 holds; the last step adds the two 16-lane rows of the half (float
+// addition commutes, so both rows get the same bits).  DPP / permlane moves only: no LDS round trips.
+template <int CTRL>
+__device__ __forceinline__ float lssd_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
 __device__ __forceinline__ float lssd_sum32(float v) {
-#pragma unroll
-  for (int step = 1; step < 32; step <<= 1) v = v + __shfl_xor(v, step, 32);
-  return v;
+  v = v + lssd_dpp<0xB1>(v);   // quad_perm [1,0,3,2]   : i ^ 1
+  v = v + lssd_dpp<0x4E>(v);   // quad_perm [2,3,0,1]   : i ^ 2
+  v = v + lssd_dpp<0x141>(v);  // row_half_mirror       : i ^ 7  (== i ^ 4 here)
+  v = v + lssd_dpp<0x140>(v);  // row_mirror            : i ^ 15 (== i ^ 8 here)
+  // rows are uniform now; v_permlane16_swap (gfx950) exchanges row 1 of one copy with row 0 of the other
+  // (and row 3 with row 2), so the two copies hold the two row totals of each half
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ int lssd_count32(bool pred) {
   const unsigned long long b = __ballot(pred);
@@ -254,17 +267,18 @@ __device__ bool lssd_track_point(const Pyr16View& OLD, const Pyr16View& CUR, int
   for (int level = prm.levels; level >= 0; level--) {
     if (!__any(valid)) break;
     const float scale = (float)(1 << level);
+    const float inv_scale = 1.f / scale;  // a power of two: x * inv_scale == x / scale bit for bit
     const Lvl16 im1 = lssd_level(OLD, stream, level), im2 = lssd_level(CUR, stream, level);
     float data = -1.f, M0 = 0.f, M1 = 0.f, M2 = 0.f;
     const bool lvl_active = valid;  // the reference leaves the level loop once the patch is invalid
     float s0 = t0, s1 = t1;         // translation at this level's scale
     if (lvl_active) {
-      s0 = t0 / scale;
-      s1 = t1 / scale;
+      s0 = t0 * inv_scale;
+      s1 = t1 * inv_scale;
     }
     // ---- OpticalFlowPatch::setFromImage (patch.h:75-131)
     {
-      const float x = pinx / scale + patx, y = piny / scale + paty;
+      const float x = pinx * inv_scale + patx, y = piny * inv_scale + paty;
       const bool inb = valid && has_pt && lssd_in_bounds(im1, x, y, 2.f);
       float val = 0.f, gx = 0.f, gy = 0.f;
       if (inb) {
