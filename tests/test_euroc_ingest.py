@@ -1,0 +1,240 @@
+"""Ingestion in front of the path: libvsf_io.so against the formats' own definitions.
+PARITY UNPINNED against the reference's libraries (OpenCV/libpng, fast-cpp-csv-parser, nlohmann::json,
+yaml-cpp, Eigen are all absent); the PNG decoder is checked against a writer built from the PNG
+specification (tests/_png.py) and, when importable, against Pillow's independent decoder/encoder."""
+import ctypes as C
+import importlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _png
+
+
+@pytest.fixture(scope="module")
+def euroc(vsf):
+    return importlib.import_module("vi_slam_amd.euroc")
+
+
+def test_io_abi_exports(euroc):
+    L = euroc.io_lib()
+    hdr = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "include", "vsf_io.h")).read()
+    for name in euroc.IO_ABI_SYMBOLS:
+        assert hasattr(L, name) and (name + "(") in hdr
+    import re
+    code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(vsf_[a-z0-9_]+)\s*\(", code))
+    assert declared == set(euroc.IO_ABI_SYMBOLS)
+
+
+@pytest.mark.parametrize("depth", [8, 16, 1, 2, 4])
+@pytest.mark.parametrize("w,h", [(752, 480), (33, 17), (1, 1), (7, 5)])
+def test_png_gray_all_filters(euroc, depth, w, h):
+    rng = np.random.default_rng(depth * 1000 + w)
+    img = rng.integers(0, 1 << depth, (h, w))
+    if depth == 8 and w > 100:  # smooth content so every filter type matters
+        yy, xx = np.mgrid[0:h, 0:w]
+        img = ((np.sin(xx / 17.0) + np.cos(yy / 11.0)) * 60 + 128 + rng.integers(0, 5, (h, w))).astype(np.int64) & 255
+    expect = {8: img, 16: img >> 8, 1: img * 255, 2: img * 85, 4: img * 17}[depth].astype(np.uint8)
+    for filters in ((0, 1, 2, 3, 4), (4,), (3, 1), (2,)):
+        data = _png.encode(img, depth, 0, filters, idat_split=97 if w > 30 else 0)
+        assert euroc.png_info(data) == (w, h, depth, 0)
+        assert np.array_equal(euroc.png_decode_gray8(data), expect)
+
+
+@pytest.mark.parametrize("depth", [8, 16])
+def test_png_gray_alpha_drops_alpha(euroc, depth):
+    rng = np.random.default_rng(depth)
+    img = rng.integers(0, 1 << depth, (9, 13, 2))
+    data = _png.encode(img, depth, 4, (1, 4, 3))
+    expect = (img[:, :, 0] >> (depth - 8)).astype(np.uint8)
+    assert np.array_equal(euroc.png_decode_gray8(data), expect)
+
+
+def test_png_against_pillow(euroc, tmp_path):
+    PIL = pytest.importorskip("PIL.Image")
+    rng = np.random.default_rng(4)
+    yy, xx = np.mgrid[0:120, 0:160]
+    img = ((xx * 3 + yy * 5) % 251 + rng.integers(0, 4, (120, 160))).astype(np.uint8)
+    # Pillow-written file -> our decoder; our test writer -> Pillow's decoder
+    p = str(tmp_path / "a.png")
+    PIL.fromarray(img, "L").save(p, optimize=True)
+    assert np.array_equal(euroc.png_decode_gray8(open(p, "rb").read()), img)
+    q = str(tmp_path / "b.png")
+    open(q, "wb").write(_png.encode(img, 8, 0, (4, 3, 2, 1, 0)))
+    assert np.array_equal(np.asarray(PIL.open(q)), img)
+    # 16-bit: OpenCV's 8-bit read keeps the high byte
+    img16 = (rng.integers(0, 65536, (20, 30))).astype(np.uint16)
+    r = str(tmp_path / "c.png")
+    PIL.fromarray(img16).save(r)
+    assert np.array_equal(euroc.png_decode_gray8(open(r, "rb").read()), (img16 >> 8).astype(np.uint8))
+
+
+def test_png_errors(euroc):
+    img = np.arange(35, dtype=np.uint8).reshape(5, 7)
+    good = _png.encode(img)
+    E = euroc.VsfIoError
+    with pytest.raises(E) as e:
+        euroc.png_decode_gray8(b"not a png at all")
+    assert e.value.code == euroc.IO_E_FORMAT
+    bad_crc = bytearray(good)
+    bad_crc[40] ^= 1
+    with pytest.raises(E):
+        euroc.png_decode_gray8(bytes(bad_crc))
+    with pytest.raises(E):  # truncated: IEND missing
+        euroc.png_decode_gray8(good[:-12])
+    with pytest.raises(E):
+        euroc.png_decode_gray8(good[:30])
+    # RGB is recognised and refused, not mis-decoded
+    import struct, zlib
+    ihdr = struct.pack(">IIBBBBB", 2, 1, 8, 2, 0, 0, 0)
+    rgb = b"\x89PNG\r\n\x1a\n" + _png._chunk(b"IHDR", ihdr) + _png._chunk(b"IDAT", zlib.compress(b"\0" + bytes(6))) + \
+        _png._chunk(b"IEND", b"")
+    with pytest.raises(E) as e:
+        euroc.png_decode_gray8(rgb)
+    assert e.value.code == euroc.IO_E_UNSUPPORTED
+    # too few rows in the compressed stream
+    short = b"\x89PNG\r\n\x1a\n" + _png._chunk(b"IHDR", struct.pack(">IIBBBBB", 7, 5, 8, 0, 0, 0, 0)) + \
+        _png._chunk(b"IDAT", zlib.compress(bytes(8 * 4))) + _png._chunk(b"IEND", b"")
+    with pytest.raises(E):
+        euroc.png_decode_gray8(short)
+    # ancillary chunks are skipped
+    withtext = _png.encode(img, extra_chunks=[(b"tEXt", b"Comment\0hello"), (b"gAMA", struct.pack(">I", 45455))])
+    assert np.array_equal(euroc.png_decode_gray8(withtext), img)
+
+
+CALIB = {"value0": {"T_imu_cam": [], "intrinsics": [
+    {"camera_type": "ds", "intrinsics": {"fx": 349.7560023050409, "fy": 348.72454229977037, "cx": 365.89440762590149,
+                                         "cy": 249.32995565708704, "xi": -0.2409573942178872, "alpha": 0.566996899163044}},
+    {"camera_type": "ds", "intrinsics": {"fx": 1.0, "fy": 1.0, "cx": 0.0, "cy": 0.0, "xi": 0.0, "alpha": 0.5}}],
+    "resolution": [[752, 480], [752, 480]], "vignette": [], "calib_accel_bias": [1e-3, -2.5E+2, 0]}}
+
+SENSOR_YAML = """# General sensor definitions.
+sensor_type: camera
+comment: VI-Sensor cam0 (MT9M034)
+
+# Sensor extrinsics wrt. the body-frame.
+T_BS:
+  cols: 4
+  rows: 4
+  data: [0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975,
+         0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768,
+        -0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949,
+         0.0, 0.0, 0.0, 1.0]
+
+# Camera specific definitions.
+rate_hz: 20
+resolution: [752, 480]
+"""
+
+
+def make_dataset(root, frames, t0=1403715273262142976, dt=50000000, crlf=True, sensor=SENSOR_YAML):
+    cam0 = os.path.join(root, "mav0", "cam0")
+    os.makedirs(os.path.join(cam0, "data"), exist_ok=True)
+    nl = "\r\n" if crlf else "\n"
+    lines = ["#timestamp [ns],filename"]
+    for k, fr in enumerate(frames):
+        ts = t0 + k * dt
+        lines.append("%d,%d.png" % (ts, ts))
+        open(os.path.join(cam0, "data", "%d.png" % ts), "wb").write(_png.encode(fr, 8, 0, (k % 5, 4, 1)))
+    open(os.path.join(cam0, "data.csv"), "w", newline="").write(nl.join(lines) + nl)
+    if sensor is not None:
+        open(os.path.join(cam0, "sensor.yaml"), "w").write(sensor)
+    calib = os.path.join(root, "calib.json")
+    json.dump(CALIB, open(calib, "w"))
+    return calib
+
+
+def test_provider_reads_what_was_written(euroc, synth, tmp_path):
+    w, h = 96, 64
+    frames, _ = synth.sequence(5, w, h, 4)
+    root = str(tmp_path / "V1_01_easy")
+    calib = make_dataset(root, frames)
+    mask = np.zeros((h, w), np.uint8)
+    mask[:, 40:] = 11
+    mask[:10] = 10     # not above the threshold
+    mask[20:30, :5] = 200
+    mpath = str(tmp_path / "mask.png")
+    open(mpath, "wb").write(_png.encode(mask))
+    dp = euroc.EurocKimeraDataProvider(root, calib, mpath)
+    assert dp.size == 4 and dp.frame_size() == (w, h)
+    cam = dp.camera_model_
+    i0 = CALIB["value0"]["intrinsics"][0]["intrinsics"]
+    assert (cam.fx, cam.fy, cam.cx, cam.cy, cam.xi, cam.alpha) == tuple(i0[k] for k in ("fx", "fy", "cx", "cy", "xi", "alpha"))
+    assert (cam.width, cam.height) == (752, 480)
+    assert np.array_equal(dp.mask_image_, np.where(mask > 10, 255, 0).astype(np.uint8))
+    for k in range(4):
+        inp = dp.GetInput()
+        assert inp.timestamp_ == float(1403715273262142976 + k * 50000000) * 1e-9
+        assert np.array_equal(inp.frame_, frames[k])
+        assert inp.mask_ is dp.mask_image_
+    assert dp.GetInput() is None and dp.GetInput(4) is None      # std::nullopt past the last line
+    again = dp.GetInput(2)                                        # by index: no state change
+    assert np.array_equal(again.frame_, frames[2]) and dp.last_index_ == 4
+    assert dp.entry(1) == (1403715273262142976 + 50000000, "%d.png" % (1403715273262142976 + 50000000))
+
+
+def test_sensor_pose_quirk_and_fallback(euroc, synth, tmp_path):
+    frames, _ = synth.sequence(5, 32, 24, 1)
+    root = str(tmp_path / "a")
+    calib = make_dataset(root, frames)
+    R, t = euroc.EurocKimeraDataProvider(root, calib).GetSensorPose()
+    d = [float(x) for x in SENSOR_YAML.split("[")[1].split("]")[0].replace("\n", " ").split(",")]
+    m = np.array([[d[0], d[1], d[2]], [d[4], d[5], d[5]], [d[8], d[9], d[10]]])   # (1,2) <- data[5], as the reference
+    assert np.allclose(t, [d[3], d[7], d[11]], rtol=0, atol=0)
+    assert np.allclose(R @ R.T, np.eye(3), atol=1e-12) and abs(np.linalg.det(R) - 1) < 1e-12
+    # same rotation as an independent matrix -> quaternion -> matrix (trace branch: this matrix has trace > 0)
+    tr = np.trace(m)
+    qw = np.sqrt(tr + 1) / 2
+    q = np.array([(m[2, 1] - m[1, 2]) / (4 * qw), (m[0, 2] - m[2, 0]) / (4 * qw), (m[1, 0] - m[0, 1]) / (4 * qw), qw])
+    q /= np.linalg.norm(q)
+    x, y, z, wq = q
+    ref = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * wq), 2 * (x * z + y * wq)],
+                    [2 * (x * y + z * wq), 1 - 2 * (x * x + z * z), 2 * (y * z - x * wq)],
+                    [2 * (x * z - y * wq), 2 * (y * z + x * wq), 1 - 2 * (x * x + y * y)]])
+    assert np.allclose(R, ref, atol=1e-14)
+    # missing / malformed sensor.yaml -> identity (the reference's catch block)
+    for sensor in (None, "T_BS:\n  data: [1, 2, 3]\n", "nothing: here\n"):
+        root2 = str(tmp_path / ("b%d" % hash(sensor)))
+        calib2 = make_dataset(root2, frames, sensor=sensor)
+        R2, t2 = euroc.EurocKimeraDataProvider(root2, calib2).GetSensorPose()
+        assert np.array_equal(R2, np.eye(3)) and np.array_equal(t2, np.zeros(3))
+
+
+def test_provider_errors(euroc, synth, tmp_path):
+    frames, _ = synth.sequence(5, 32, 24, 2)
+    E = euroc.VsfIoError
+    root = str(tmp_path / "ok")
+    calib = make_dataset(root, frames, crlf=False)
+    assert euroc.EurocKimeraDataProvider(root, calib).size == 2
+    with pytest.raises(E) as e:
+        euroc.EurocKimeraDataProvider(str(tmp_path / "missing"), calib)
+    assert e.value.code == euroc.IO_E_FILE
+    # header with an extra column / row with a bad timestamp / missing calibration fields / other camera type
+    csv = os.path.join(root, "mav0", "cam0", "data.csv")
+    good = open(csv).read()
+    open(csv, "w").write(good.replace("filename", "filename,extra"))
+    with pytest.raises(E):
+        euroc.EurocKimeraDataProvider(root, calib)
+    open(csv, "w").write(good.replace("1403715273262142976,", "14037x,", 1))
+    with pytest.raises(E):
+        euroc.EurocKimeraDataProvider(root, calib)
+    open(csv, "w").write(good)
+    bad = json.loads(json.dumps(CALIB))
+    bad["value0"]["intrinsics"][0]["camera_type"] = "pinhole"
+    json.dump(bad, open(calib, "w"))
+    with pytest.raises(E) as e:
+        euroc.EurocKimeraDataProvider(root, calib)
+    assert e.value.code == euroc.IO_E_UNSUPPORTED
+    open(calib, "w").write("{\"value0\": {")
+    with pytest.raises(E):
+        euroc.EurocKimeraDataProvider(root, calib)
+    # a listed frame that is missing on disk fails at GetInput, not at open
+    json.dump(CALIB, open(calib, "w"))
+    dp = euroc.EurocKimeraDataProvider(root, calib)
+    os.remove(os.path.join(root, "mav0", "cam0", "data", dp.entry(1)[1]))
+    assert dp.GetInput() is not None
+    with pytest.raises(E):
+        dp.GetInput()

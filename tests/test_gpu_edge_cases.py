@@ -130,3 +130,35 @@ def test_table_larger_than_the_lk_grid(vsf, oracle, synth):
     rc, rstats = trk.track_pair(T, frames[0], frames[1])
     assert n == T.n.value and tuple(stats) == tuple(rstats)
     assert np.array_equal(ids[:n], T.ids[:n]) and np.array_equal(xy[:n], T.xy[:n])
+
+
+def test_strided_host_frames_equal_packed_ones(vsf, synth):
+    """cv::Mat::step > cols (an ROI of a wider image): frames, previous frames and masks with a row stride."""
+    w, h = 200, 150
+    frames, _ = synth.sequence(17, w, h, 3)
+    wide = np.full((3, h, w + 37), 7, np.uint8)
+    wide[:, :, 5:5 + w] = frames
+    mask = np.full((h, w), 255, np.uint8)
+    mask[:, :60] = 0
+    wmask = np.zeros((h, w + 11), np.uint8)
+    wmask[:, 3:3 + w] = mask
+
+    def run(fr, mk):
+        det = vsf.FeatureDetectorShiTomasiBucketing(2, 2, 80, 5.0, w, h, capacity=256)
+        trk = vsf.FeatureTrackerLucasKanade(30, 0.01, 21, 3, 1.0, w, h, capacity=256)
+        trk2 = vsf.FeatureTrackerLucasKanade(30, 0.01, 21, 3, 1.0, w, h, capacity=256)
+        db, db2 = vsf.FeatureDatabase(256), vsf.FeatureDatabase(256)
+        out = []
+        for k in range(3):
+            trk.Track(db, fr(k))
+            det.UpdateDetection(db, fr(k), mk)
+            out.append(db.as_dict())
+        db2.set(db.ids[:db.n].copy(), db.xy[:db.n].copy(), db.age[:db.n].copy())
+        trk2.Track(db2, fr(1), fr(2))
+        out.append(db2.as_dict())
+        return out
+
+    packed = run(lambda k: frames[k], mask)
+    strided = run(lambda k: wide[k, :, 5:5 + w], wmask[:, 3:3 + w])
+    assert not wide[0, :, 5:5 + w].flags["C_CONTIGUOUS"]
+    assert packed == strided and len(packed[-1]) > 10

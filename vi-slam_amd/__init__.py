@@ -156,34 +156,43 @@ class Context:
             raise VsfError(rc, lib().vsf_last_error(self._h).decode())
 
     # ---- single-stream host API ----
+    @staticmethod
+    def _frame(img):
+        """A 2-D uint8 array whose rows are contiguous is passed as it is (row stride = cv::Mat::step, e.g. an
+        ROI view of a wider image); anything else is copied to a packed array first."""
+        img = np.asarray(img)
+        if img.dtype != np.uint8 or img.ndim != 2 or img.strides[1] != 1 or img.strides[0] < img.shape[1]:
+            img = np.ascontiguousarray(img, np.uint8)
+        return img, img.strides[0]
+
     def track(self, img, ids, xy, age, n):
-        img = np.ascontiguousarray(img, np.uint8)
+        img, stride = self._frame(img)
         h, w = img.shape
         nn = C.c_int32(n)
         st = VsfTrackStats()
-        self._chk(lib().vsf_track(self._h, _vp(img), w, h, w, _vp(ids), _vp(xy), _vp(age),
+        self._chk(lib().vsf_track(self._h, _vp(img), w, h, stride, _vp(ids), _vp(xy), _vp(age),
                                   C.byref(nn), C.byref(st)))
         return nn.value, (st.input, st.forward, st.backward, st.verified)
 
     def track_pair(self, prev, cur, ids, xy, age, n):
-        prev = np.ascontiguousarray(prev, np.uint8)
-        cur = np.ascontiguousarray(cur, np.uint8)
+        prev, pstride = self._frame(prev)
+        cur, cstride = self._frame(cur)
         h, w = cur.shape
         nn = C.c_int32(n)
         st = VsfTrackStats()
-        self._chk(lib().vsf_track_pair(self._h, _vp(prev), w, _vp(cur), w, w, h, _vp(ids), _vp(xy),
+        self._chk(lib().vsf_track_pair(self._h, _vp(prev), pstride, _vp(cur), cstride, w, h, _vp(ids), _vp(xy),
                                        _vp(age), C.byref(nn), C.byref(st)))
         return nn.value, (st.input, st.forward, st.backward, st.verified)
 
     def detect(self, img, ids, xy, age, n, mask=None):
-        img = np.ascontiguousarray(img, np.uint8)
+        img, stride = self._frame(img)
         h, w = img.shape
         nn = C.c_int32(n)
         mptr, mstride = None, 0
         if mask is not None:
-            mask = np.ascontiguousarray(mask, np.uint8)
-            mptr, mstride = _vp(mask), mask.shape[1]
-        self._chk(lib().vsf_detect(self._h, _vp(img), w, h, w, mptr, mstride, _vp(ids), _vp(xy),
+            mask, mstride = self._frame(mask)
+            mptr = _vp(mask)
+        self._chk(lib().vsf_detect(self._h, _vp(img), w, h, stride, mptr, mstride, _vp(ids), _vp(xy),
                                    _vp(age), C.byref(nn), len(ids)))
         return nn.value
 

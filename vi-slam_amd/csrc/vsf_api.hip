@@ -48,6 +48,7 @@ struct vsf_ctx {
   int cur = 0;
   bool has_prev = false;
   uint8_t* own_frame[2] = {};  // host-API staging of stream 0 (ping-pong: previous frame stays resident)
+  uint8_t* h_stage = nullptr;  // pinned host buffer for strided host frames, allocated on first use
   // stateless pair / debug buffers (single stream), allocated lazily
   PyrSet pair_pyr[2];
   uint8_t* pair_frame[2] = {};
@@ -484,8 +485,17 @@ void host_grid(int w, int h, int cols, int rows, std::vector<int4>& rects, std::
     }
 }
 
+// Host frame -> device, rows packed.  A contiguous frame goes in one 1-D copy; a strided one is packed
+// into a pinned staging buffer first (hipMemcpy2D from pageable memory copies row by row: 4.5 ms for a
+// 752x480 frame, measured, against ~0.1 ms this way).
 int upload_frame(vsf_ctx* c, uint8_t* dst, const uint8_t* img, int w, int h, int stride) {
-  HIPCHK(c, hipMemcpy2D(dst, (size_t)w, img, (size_t)stride, (size_t)w, (size_t)h, hipMemcpyHostToDevice));
+  if (stride == w) {
+    HIPCHK(c, hipMemcpy(dst, img, (size_t)w * h, hipMemcpyHostToDevice));
+    return VSF_OK;
+  }
+  if (!c->h_stage) HIPCHK(c, hipHostMalloc((void**)&c->h_stage, (size_t)c->p.width * c->p.height, hipHostMallocDefault));
+  for (int y = 0; y < h; y++) memcpy(c->h_stage + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+  HIPCHK(c, hipMemcpy(dst, c->h_stage, (size_t)w * h, hipMemcpyHostToDevice));
   return VSF_OK;
 }
 
@@ -596,6 +606,7 @@ void vsf_destroy(vsf_ctx* c) {
     if (c->own_frame[i]) (void)hipFree(c->own_frame[i]);
     if (c->pair_frame[i]) (void)hipFree(c->pair_frame[i]);
   }
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   void* lssd_bufs[] = {c->d_lssd_ids, c->d_lssd_xy, c->d_lssd_n};
   for (void* b : lssd_bufs)
     if (b) (void)hipFree(b);
