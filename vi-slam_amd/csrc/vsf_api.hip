@@ -205,8 +205,15 @@ int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStr
     const long long sst = (l == 1) ? f.sstride : (long long)c->lp[l - 1] * c->lh[l - 1];
     const int sp = (l == 1) ? f.pitch : c->lp[l - 1];
     dim3 grid((c->lw[l] + PD_TW - 1) / PD_TW, (c->lh[l] + PD_TH - 1) / PD_TH, streams);
-    hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
-                       ps.lv[l], (long long)c->lp[l] * c->lh[l], c->lp[l], c->lw[l], c->lh[l]);
+    const long long dst_sst = (long long)c->lp[l] * c->lh[l];
+    const bool aligned = ((uintptr_t)src % 4 == 0) && sst % 4 == 0 && sp % 4 == 0 && c->lw[l - 1] % 4 == 0 &&
+                         c->lw[l - 1] >= 8 && ((uintptr_t)ps.lv[l] % 4 == 0) && dst_sst % 4 == 0 && c->lp[l] % 4 == 0;
+    if (aligned)
+      hipLaunchKernelGGL(pyr_down_dword_kernel, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
+                         ps.lv[l], dst_sst, c->lp[l], c->lw[l], c->lh[l]);
+    else
+      hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
+                         ps.lv[l], dst_sst, c->lp[l], c->lw[l], c->lh[l]);
   }
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
