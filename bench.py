@@ -32,6 +32,7 @@ MAX_FEATURES = 300
 GRID = (4, 4)
 MIN_DIST = 10.0
 HBM_PEAK = 8.0e12
+VALU_PEAK = 256 * 4 * 2.4e9 / 2  # wave64 vector instructions per second (SIMD-32: 2 cycles each)
 
 
 def pyramid_bytes(w, h, levels):
@@ -198,6 +199,7 @@ def main():
         lk_avg = (lk_ms / lk_n) * 1e-3 if lk_n else float("nan")
         achieved = alg_lk * B / lk_avg / 1e9 if lk_n else 0.0
         traffic = None
+        valu = None
         tpath = None
         if args.tracker == "lk":
             tpath = os.path.join(ROOT, "profiles", "lk_traffic.json")
@@ -206,6 +208,13 @@ def main():
                 tj = json.load(open(tpath))
                 if tj.get("streams") == B:
                     traffic = tj.get("hbm_bytes_per_launch")
+                    if tj.get("valu_insts_per_launch") and lk_n:
+                        # the kernel is bound by vector-instruction issue, not bytes: committed SQ_INSTS_VALU count
+                        # per launch over the live launch time, against one wave64 VALU instruction per 2 cycles
+                        # per SIMD (4 SIMDs x 256 CUs x 2.4 GHz, MI355X_MICROARCH.md)
+                        rate = tj["valu_insts_per_launch"] / lk_avg
+                        valu = {"insts_per_launch": tj["valu_insts_per_launch"], "achieved_ginst_s": rate / 1e9,
+                                "peak_ginst_s": VALU_PEAK / 1e9, "frac": rate / VALU_PEAK}
             except Exception:
                 traffic = None
         line = {
@@ -231,7 +240,8 @@ def main():
                        "mean_features_per_stream": mean_feats, "verified_fraction": kept_frac},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
-                         "avg_launch_ms": lk_avg * 1e3, "algorithmic_bytes_per_launch": alg_lk * B},
+                         "avg_launch_ms": lk_avg * 1e3, "algorithmic_bytes_per_launch": alg_lk * B,
+                         "valu_issue": valu},
             "step_hbm_frac": alg_step * value / world / HBM_PEAK,
             "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()},
         }

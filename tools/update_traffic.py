@@ -11,6 +11,14 @@ def lk(counter):
     raise SystemExit("no lk_fb_kernel row for " + counter)
 name, f = lk("FETCH_SIZE")
 _, w = lk("WRITE_SIZE")
+def sq(counter):
+    path = os.path.join(root, "gpurun_out", "prof_%s_pmc_SQ_INSTS_VALU.csv" % tag)
+    if not os.path.exists(path):
+        return None
+    for row in csv.DictReader(open(path)):
+        if "lk_fb_kernel" in row["kernel"] and row["counter"] == counter:
+            return float(row["mean_per_launch"])
+    return None
 P = 752 * 480 + 376 * 240 + 188 * 120 + 94 * 60
 out = {
     "kernel": name.replace("void vsf::", ""), "streams": streams,
@@ -18,6 +26,8 @@ out = {
     "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
     "hbm_bytes_per_launch": int((f + w) * 1024),
     "algorithmic_bytes_per_launch": (2 * P + 24 * 300) * streams,
+    "valu_insts_per_launch": sq("SQ_INSTS_VALU"), "salu_insts_per_launch": sq("SQ_INSTS_SALU"),
+    "lds_insts_per_launch": sq("SQ_INSTS_LDS"), "waves_per_launch": sq("SQ_WAVES"),
     "collection": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate runs of `python3 bench.py --steps 3 "
                   "--warmup 2 --no-cpu` (tools/profile_round.sh %s), mean over the launches; summaries in "
                   "profiles/%s_pmc_FETCH_SIZE.csv / _WRITE_SIZE.csv" % (tag, tag),
