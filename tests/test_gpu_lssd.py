@@ -203,3 +203,26 @@ def test_golden_on_gpu(vsf, path):
         det.UpdateDetection(db, frames[k])
         assert np.array_equal(db.ids[:db.n], g["lssd_det%d_ids" % k]) and np.array_equal(db.xy[:db.n], g["lssd_det%d_xy" % k])
         assert np.array_equal(db.age[:db.n], g["lssd_det%d_age" % k])
+
+
+def test_anms_detector_with_lssd_tracker_in_one_context(vsf, oracle, synth):
+    """Both "next" components behind one context (what KimeraFrontend instantiates): batch_step on 3 streams."""
+    import torch
+    w, h, B, T = 320, 240, 3, 4
+    frames = np.stack([synth.sequence(300 + b, w, h, T)[0] for b in range(B)], 1)
+    p = _params(vsf, w, h, detector_kind=vsf.DETECTOR_ANMS, max_features=100, min_distance=9.0, streams=B)
+    ctx = vsf.Context(p)
+    dev = torch.from_numpy(frames).cuda()
+    dets = [oracle.AnmsDetector(100, 9.0) for _ in range(B)]
+    trks = [oracle.LssdTracker(mode=oracle.LSSD_TREE) for _ in range(B)]
+    tabs = [oracle.FeatureTable(ctx.capacity) for _ in range(B)]
+    for t in range(T):
+        ctx.batch_step(dev[t].data_ptr(), h * w, w, torch.cuda.current_stream().cuda_stream)
+        ids, xy, age, n, _ = ctx.batch_download()
+        for b in range(B):
+            trks[b].track(tabs[b], frames[t, b])
+            assert dets[b].update_detection(tabs[b], frames[t, b]) in (0, 1)
+            got = {int(i): (float(q[0]), float(q[1]), int(a)) for i, q, a in zip(ids[b, :n[b]], xy[b, :n[b]], age[b, :n[b]])}
+            assert got == tabs[b].as_dict(), "step %d stream %d" % (t, b)
+    assert (ctx.batch_status() == 0).all()
+    ctx.close()
