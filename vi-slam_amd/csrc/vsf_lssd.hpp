@@ -96,38 +96,44 @@ __device__ __forceinline__ Lvl16 lssd_level(const Pyr16View& P, int stream, int 
   }
   return L;
 }
+// L0: the level is the caller's u8 frame read as v << 8; otherwise a u16 level.  Offsets fit 32 bits (a level of
+// one stream is far below 4 GB), which keeps the address arithmetic to one multiply-add per pixel.
+template <bool L0>
 __device__ __forceinline__ float lssd_px(const Lvl16& im, int x, int y) {
-  if (im.p8) return (float)((int)im.p8[(long long)y * im.pitch + x] << 8);
-  return (float)im.p16[(long long)y * im.pitch + x];
+  const unsigned int off = (unsigned int)(y * im.pitch + x);
+  if (L0) return (float)((int)im.p8[off] << 8);
+  return (float)im.p16[off];
 }
 // basalt::Image::InBounds(p, border), floating point p
 __device__ __forceinline__ bool lssd_in_bounds(const Lvl16& im, float x, float y, float border) {
   return border <= x && x < ((float)im.w - border - 1.f) && border <= y && y < ((float)im.h - border - 1.f);
 }
 // basalt::Image::interp<float>
+template <bool L0>
 __device__ __forceinline__ float lssd_interp(const Lvl16& im, float x, float y) {
   const int ix = (int)x, iy = (int)y;
   const float dx = x - (float)ix, dy = y - (float)iy;
   const float ddx = 1.f - dx, ddy = 1.f - dy;
-  return ddx * ddy * lssd_px(im, ix, iy) + ddx * dy * lssd_px(im, ix, iy + 1) + dx * ddy * lssd_px(im, ix + 1, iy) +
-         dx * dy * lssd_px(im, ix + 1, iy + 1);
+  return ddx * ddy * lssd_px<L0>(im, ix, iy) + ddx * dy * lssd_px<L0>(im, ix, iy + 1) + dx * ddy * lssd_px<L0>(im, ix + 1, iy) +
+         dx * dy * lssd_px<L0>(im, ix + 1, iy + 1);
 }
 // basalt::Image::interpGrad<float>
+template <bool L0>
 __device__ __forceinline__ void lssd_interp_grad(const Lvl16& im, float x, float y, float (&out)[3]) {
   const int ix = (int)x, iy = (int)y;
   const float dx = x - (float)ix, dy = y - (float)iy;
   const float ddx = 1.f - dx, ddy = 1.f - dy;
-  const float px0y0 = lssd_px(im, ix, iy), px1y0 = lssd_px(im, ix + 1, iy);
-  const float px0y1 = lssd_px(im, ix, iy + 1), px1y1 = lssd_px(im, ix + 1, iy + 1);
+  const float px0y0 = lssd_px<L0>(im, ix, iy), px1y0 = lssd_px<L0>(im, ix + 1, iy);
+  const float px0y1 = lssd_px<L0>(im, ix, iy + 1), px1y1 = lssd_px<L0>(im, ix + 1, iy + 1);
   out[0] = ddx * ddy * px0y0 + ddx * dy * px0y1 + dx * ddy * px1y0 + dx * dy * px1y1;
-  const float pxm1y0 = lssd_px(im, ix - 1, iy), pxm1y1 = lssd_px(im, ix - 1, iy + 1);
+  const float pxm1y0 = lssd_px<L0>(im, ix - 1, iy), pxm1y1 = lssd_px<L0>(im, ix - 1, iy + 1);
   const float res_mx = ddx * ddy * pxm1y0 + ddx * dy * pxm1y1 + dx * ddy * px0y0 + dx * dy * px0y1;
-  const float px2y0 = lssd_px(im, ix + 2, iy), px2y1 = lssd_px(im, ix + 2, iy + 1);
+  const float px2y0 = lssd_px<L0>(im, ix + 2, iy), px2y1 = lssd_px<L0>(im, ix + 2, iy + 1);
   const float res_px = ddx * ddy * px1y0 + ddx * dy * px1y1 + dx * ddy * px2y0 + dx * dy * px2y1;
   out[1] = 0.5f * (res_px - res_mx);
-  const float px0ym1 = lssd_px(im, ix, iy - 1), px1ym1 = lssd_px(im, ix + 1, iy - 1);
+  const float px0ym1 = lssd_px<L0>(im, ix, iy - 1), px1ym1 = lssd_px<L0>(im, ix + 1, iy - 1);
   const float res_my = ddx * ddy * px0ym1 + ddx * dy * px0y0 + dx * ddy * px1ym1 + dx * dy * px1y0;
-  const float px0y2 = lssd_px(im, ix, iy + 2), px1y2 = lssd_px(im, ix + 1, iy + 2);
+  const float px0y2 = lssd_px<L0>(im, ix, iy + 2), px1y2 = lssd_px<L0>(im, ix + 1, iy + 2);
   const float res_py = ddx * ddy * px0y1 + ddx * dy * px0y2 + dx * ddy * px1y1 + dx * dy * px1y2;
   out[2] = 0.5f * (res_py - res_my);
 }
@@ -253,6 +259,133 @@ __device__ inline void lssd_ldlt_inverse3(const float (&H)[3][3], float (&Hinv)[
     for (int j = 0; j < 3; j++) Hinv[i][j] = X[i][j];
 }
 
+// One pyramid level of TrackPoint for the feature of this half-wavefront: the patch of the old image
+// (OpticalFlowPatch::setFromImage, patch.h:75-131) and TrackPointAtLevel (:114-146).
+struct LssdTrack {
+  float L00, L01, L10, L11;  // transform.linear()
+  float t0, t1;              // transform.translation(), full-resolution pixels
+  bool valid;                // patch_valid
+};
+
+template <bool L0>
+__device__ __forceinline__ void lssd_level_pass(const Lvl16& im1, const Lvl16& im2, int level, float pinx, float piny,
+                                                float patx, float paty, bool has_pt, LssdTrack& T,
+                                                const LssdParams& prm) {
+  const float scale = (float)(1 << level);
+  const float inv_scale = 1.f / scale;  // a power of two: x * inv_scale == x / scale bit for bit
+  float data = -1.f, M0 = 0.f, M1 = 0.f, M2 = 0.f;
+  bool valid = T.valid;
+  const bool lvl_active = valid;  // the reference leaves the level loop once the patch is invalid
+  float L00 = T.L00, L01 = T.L01, L10 = T.L10, L11 = T.L11;
+  float s0 = T.t0, s1 = T.t1;  // translation at this level's scale
+  if (lvl_active) {
+    s0 = T.t0 * inv_scale;
+    s1 = T.t1 * inv_scale;
+  }
+  // ---- OpticalFlowPatch::setFromImage (patch.h:75-131)
+  {
+    const float x = pinx * inv_scale + patx, y = piny * inv_scale + paty;
+    const bool inb = valid && has_pt && lssd_in_bounds(im1, x, y, 2.f);
+    float val = 0.f, gx = 0.f, gy = 0.f;
+    if (inb) {
+      float vg[3];
+      lssd_interp_grad<L0>(im1, x, y, vg);
+      data = vg[0];
+      val = vg[0];
+      gx = vg[1];
+      gy = vg[2];
+    }
+    const int num_valid = lssd_count32(inb);
+    const float sum = lssd_sum32(val), gsx = lssd_sum32(gx), gsy = lssd_sum32(gy);
+    const float mean_inv = (float)num_valid / sum;
+    float jx = 0.f, jy = 0.f;
+    if (data >= 0.f) {
+      const float d = data;
+      jx = ((float)num_valid * (gx * sum - gsx * d)) / (sum * sum);
+      jy = ((float)num_valid * (gy * sum - gsy * d)) / (sum * sum);
+      data = d * mean_inv;
+    }
+    const float J0 = jx, J1 = jy, J2 = jx * (-paty) + jy * patx;
+    float H[3][3], Hinv[3][3];
+    H[0][0] = lssd_sum32(J0 * J0);
+    H[0][1] = H[1][0] = lssd_sum32(J0 * J1);
+    H[0][2] = H[2][0] = lssd_sum32(J0 * J2);
+    H[1][1] = lssd_sum32(J1 * J1);
+    H[1][2] = H[2][1] = lssd_sum32(J1 * J2);
+    H[2][2] = lssd_sum32(J2 * J2);
+    lssd_ldlt_inverse3(H, Hinv);
+    M0 = (Hinv[0][0] * J0 + Hinv[0][1] * J1) + Hinv[0][2] * J2;
+    M1 = (Hinv[1][0] * J0 + Hinv[1][1] * J1) + Hinv[1][2] * J2;
+    M2 = (Hinv[2][0] * J0 + Hinv[2][1] * J1) + Hinv[2][2] * J2;
+    if (!has_pt) {
+      M0 = 0.f;
+      M1 = 0.f;
+      M2 = 0.f;
+    }
+  }
+  // ---- TrackPointAtLevel (:114-146)
+  for (int it = 0; it < prm.max_iterations; it++) {
+    if (!__any(valid)) break;
+    const float px = (L00 * patx + L01 * paty) + s0, py = (L10 * patx + L11 * paty) + s1;
+    const bool inb = valid && has_pt && lssd_in_bounds(im2, px, py, 2.f);
+    float res = -1.f, val = 0.f;
+    if (inb) {
+      res = lssd_interp<L0>(im2, px, py);
+      val = res;
+    }
+    const int num_valid = lssd_count32(inb);
+    const float sum = lssd_sum32(val);
+    const bool use = has_pt && res >= 0.f && data >= 0.f;
+    float r = 0.f;
+    if (use) r = ((float)num_valid * res) / sum - data;
+    const int num_res = lssd_count32(use);
+    // slots without a pattern point hold +0 like the oracle's padding (not the -0 of (-0) * 0)
+    const float inc0 = lssd_sum32(has_pt ? (-M0) * r : 0.f), inc1 = lssd_sum32(has_pt ? (-M1) * r : 0.f),
+                inc2 = lssd_sum32(has_pt ? (-M2) * r : 0.f);
+    if (valid) {
+      if (num_res > LSSD_PATTERN / 2) {
+        const float theta = inc2;  // Sophus::SE2f::exp
+        float sn, cs;
+        lssd_sincos(theta, sn, cs);
+        float sbt, omcbt;
+        if (fabsf(theta) < 1e-5f) {
+          const float theta_sq = theta * theta;
+          sbt = 1.f - (1.f / 6.f) * theta_sq;
+          omcbt = 0.5f * theta - (1.f / 24.f) * theta * theta_sq;
+        } else {
+          sbt = sn / theta;
+          omcbt = (1.f - cs) / theta;
+        }
+        const float ex = sbt * inc0 - omcbt * inc1;
+        const float ey = omcbt * inc0 + sbt * inc1;
+        // transform *= SE2::exp(inc).matrix(): (2x3) * (3x3) with last row (0 0 1)
+        const float n00 = (L00 * cs + L01 * sn) + s0 * 0.f, n01 = (L00 * (-sn) + L01 * cs) + s0 * 0.f;
+        const float n10 = (L10 * cs + L11 * sn) + s1 * 0.f, n11 = (L10 * (-sn) + L11 * cs) + s1 * 0.f;
+        const float nt0 = (L00 * ex + L01 * ey) + s0 * 1.f, nt1 = (L10 * ex + L11 * ey) + s1 * 1.f;
+        L00 = n00;
+        L01 = n01;
+        L10 = n10;
+        L11 = n11;
+        s0 = nt0;
+        s1 = nt1;
+        if (!lssd_in_bounds(im2, s0, s1, 2.f)) valid = false;
+      } else {
+        valid = false;
+      }
+    }
+  }
+  T.L00 = L00;
+  T.L01 = L01;
+  T.L10 = L10;
+  T.L11 = L11;
+  T.valid = valid;
+  // TrackPoint :98/:106 scale the translation of a level that ran, whatever its outcome
+  if (lvl_active) {
+    T.t0 = s0 * scale;
+    T.t1 = s1 * scale;
+  }
+}
+
 // FrameToFrameOpticalFlow::TrackPoint (frame_to_frame_optical_flow_single_thread.cpp:84-146) for the
 // feature of this half-wavefront.  `active`: the half holds a feature (control flow below is per half:
 // the two halves of a wave may run different trip counts, lanes of a finished half idle).
@@ -261,122 +394,18 @@ __device__ bool lssd_track_point(const Pyr16View& OLD, const Pyr16View& CUR, int
   const int li = threadIdx.x & 31;
   const float patx = LSSD_PAT[li][0], paty = LSSD_PAT[li][1];
   const bool has_pt = li < LSSD_PATTERN;
-  float L00 = 1.f, L01 = 0.f, L10 = 0.f, L11 = 1.f;
-  float t0 = tx, t1 = ty;
-  bool valid = active;
+  LssdTrack T = {1.f, 0.f, 0.f, 1.f, tx, ty, active};
   for (int level = prm.levels; level >= 0; level--) {
-    if (!__any(valid)) break;
-    const float scale = (float)(1 << level);
-    const float inv_scale = 1.f / scale;  // a power of two: x * inv_scale == x / scale bit for bit
+    if (!__any(T.valid)) break;
     const Lvl16 im1 = lssd_level(OLD, stream, level), im2 = lssd_level(CUR, stream, level);
-    float data = -1.f, M0 = 0.f, M1 = 0.f, M2 = 0.f;
-    const bool lvl_active = valid;  // the reference leaves the level loop once the patch is invalid
-    float s0 = t0, s1 = t1;         // translation at this level's scale
-    if (lvl_active) {
-      s0 = t0 * inv_scale;
-      s1 = t1 * inv_scale;
-    }
-    // ---- OpticalFlowPatch::setFromImage (patch.h:75-131)
-    {
-      const float x = pinx * inv_scale + patx, y = piny * inv_scale + paty;
-      const bool inb = valid && has_pt && lssd_in_bounds(im1, x, y, 2.f);
-      float val = 0.f, gx = 0.f, gy = 0.f;
-      if (inb) {
-        float vg[3];
-        lssd_interp_grad(im1, x, y, vg);
-        data = vg[0];
-        val = vg[0];
-        gx = vg[1];
-        gy = vg[2];
-      }
-      const int num_valid = lssd_count32(inb);
-      const float sum = lssd_sum32(val), gsx = lssd_sum32(gx), gsy = lssd_sum32(gy);
-      const float mean_inv = (float)num_valid / sum;
-      float jx = 0.f, jy = 0.f;
-      if (data >= 0.f) {
-        const float d = data;
-        jx = ((float)num_valid * (gx * sum - gsx * d)) / (sum * sum);
-        jy = ((float)num_valid * (gy * sum - gsy * d)) / (sum * sum);
-        data = d * mean_inv;
-      }
-      const float J0 = jx, J1 = jy, J2 = jx * (-paty) + jy * patx;
-      float H[3][3], Hinv[3][3];
-      H[0][0] = lssd_sum32(J0 * J0);
-      H[0][1] = H[1][0] = lssd_sum32(J0 * J1);
-      H[0][2] = H[2][0] = lssd_sum32(J0 * J2);
-      H[1][1] = lssd_sum32(J1 * J1);
-      H[1][2] = H[2][1] = lssd_sum32(J1 * J2);
-      H[2][2] = lssd_sum32(J2 * J2);
-      lssd_ldlt_inverse3(H, Hinv);
-      M0 = (Hinv[0][0] * J0 + Hinv[0][1] * J1) + Hinv[0][2] * J2;
-      M1 = (Hinv[1][0] * J0 + Hinv[1][1] * J1) + Hinv[1][2] * J2;
-      M2 = (Hinv[2][0] * J0 + Hinv[2][1] * J1) + Hinv[2][2] * J2;
-      if (!has_pt) {
-        M0 = 0.f;
-        M1 = 0.f;
-        M2 = 0.f;
-      }
-    }
-    // ---- TrackPointAtLevel (:114-146)
-    for (int it = 0; it < prm.max_iterations; it++) {
-      if (!__any(valid)) break;
-      const float px = (L00 * patx + L01 * paty) + s0, py = (L10 * patx + L11 * paty) + s1;
-      const bool inb = valid && has_pt && lssd_in_bounds(im2, px, py, 2.f);
-      float res = -1.f, val = 0.f;
-      if (inb) {
-        res = lssd_interp(im2, px, py);
-        val = res;
-      }
-      const int num_valid = lssd_count32(inb);
-      const float sum = lssd_sum32(val);
-      const bool use = has_pt && res >= 0.f && data >= 0.f;
-      float r = 0.f;
-      if (use) r = ((float)num_valid * res) / sum - data;
-      const int num_res = lssd_count32(use);
-      // slots without a pattern point hold +0 like the oracle's padding (not the -0 of (-0) * 0)
-      const float inc0 = lssd_sum32(has_pt ? (-M0) * r : 0.f), inc1 = lssd_sum32(has_pt ? (-M1) * r : 0.f),
-                  inc2 = lssd_sum32(has_pt ? (-M2) * r : 0.f);
-      if (valid) {
-        if (num_res > LSSD_PATTERN / 2) {
-          const float theta = inc2;  // Sophus::SE2f::exp
-          float sn, cs;
-          lssd_sincos(theta, sn, cs);
-          float sbt, omcbt;
-          if (fabsf(theta) < 1e-5f) {
-            const float theta_sq = theta * theta;
-            sbt = 1.f - (1.f / 6.f) * theta_sq;
-            omcbt = 0.5f * theta - (1.f / 24.f) * theta * theta_sq;
-          } else {
-            sbt = sn / theta;
-            omcbt = (1.f - cs) / theta;
-          }
-          const float ex = sbt * inc0 - omcbt * inc1;
-          const float ey = omcbt * inc0 + sbt * inc1;
-          // transform *= SE2::exp(inc).matrix(): (2x3) * (3x3) with last row (0 0 1)
-          const float n00 = (L00 * cs + L01 * sn) + s0 * 0.f, n01 = (L00 * (-sn) + L01 * cs) + s0 * 0.f;
-          const float n10 = (L10 * cs + L11 * sn) + s1 * 0.f, n11 = (L10 * (-sn) + L11 * cs) + s1 * 0.f;
-          const float nt0 = (L00 * ex + L01 * ey) + s0 * 1.f, nt1 = (L10 * ex + L11 * ey) + s1 * 1.f;
-          L00 = n00;
-          L01 = n01;
-          L10 = n10;
-          L11 = n11;
-          s0 = nt0;
-          s1 = nt1;
-          if (!lssd_in_bounds(im2, s0, s1, 2.f)) valid = false;
-        } else {
-          valid = false;
-        }
-      }
-    }
-    // TrackPoint :98/:106 scale the translation of a level that ran, whatever its outcome
-    if (lvl_active) {
-      t0 = s0 * scale;
-      t1 = s1 * scale;
-    }
+    if (level == 0)
+      lssd_level_pass<true>(im1, im2, 0, pinx, piny, patx, paty, has_pt, T, prm);
+    else
+      lssd_level_pass<false>(im1, im2, level, pinx, piny, patx, paty, has_pt, T, prm);
   }
-  tx = t0;
-  ty = t1;
-  return valid;
+  tx = T.t0;
+  ty = T.t1;
+  return T.valid;
 }
 
 // The reference tracker keeps its own id -> transform map between calls
