@@ -206,6 +206,9 @@ int vsf_unproject(vsf_ctx* ctx, const vsf_camera_ds* cam, const double* xy, int3
  * on n points of a frame pair, with the context's lssd_* parameters: next_pts 2n floats, valid n bytes. */
 int vsf_debug_lssd(vsf_ctx* ctx, const uint8_t* prev, const uint8_t* next, int32_t w, int32_t h,
                    const float* prev_pts, float* next_pts, uint8_t* valid, int32_t n);
+/* The 3x3 inverse the patch set-up takes (patch.h: H_se2.ldlt().solve(Identity), Eigen's pivoted LDLT restated)
+ * on n row-major matrices: every pivot order can be checked against the oracle. */
+int vsf_debug_lssd_inverse3(vsf_ctx* ctx, const float* H, float* Hinv, int32_t n);
 /* Level `level` (1..lssd_levels) of the u16 mip pyramid (basalt ManagedImagePyr::setFromImage of the frame
  * shifted left by 8): out receives (w >> level) * (h >> level) uint16. */
 int vsf_debug_lssd_pyramid(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t level,

@@ -104,6 +104,35 @@ def test_batch_matches_per_stream_oracle(vsf, oracle, synth):
     ctx.close()
 
 
+def test_ldlt_inverse_every_pivot_order_bit_exact(vsf, oracle):
+    """Eigen's pivoted 3x3 LDLT + solve(Identity): image data nearly always pivots on the rotation entry first,
+    so the other five pivot orders (and ties, zero and negative pivots) are driven here directly."""
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    mats = []
+    for scale in ([1, 1, 1], [1, 5, 30], [30, 5, 1], [5, 30, 1], [5, 1, 30], [1, 30, 5], [30, 1, 5]):
+        for _ in range(300):
+            J = (rng.normal(size=(24, 3)) * np.array(scale)).astype(np.float32)
+            mats.append((J.T @ J).astype(np.float32))
+    mats += [np.eye(3, dtype=np.float32) * v for v in (1.0, 2.5, 0.0)]                      # ties / singular
+    mats += [np.diag(np.array(dd, np.float32)) for dd in ([1, 1, 2], [2, 1, 1], [1, 2, 2], [0, 3, 0], [-4, 1, 2])]
+    sym = rng.normal(size=(200, 3, 3)).astype(np.float32)                                   # indefinite symmetric
+    mats += list(sym + sym.transpose(0, 2, 1))
+    H = np.stack(mats).astype(np.float32)
+    ctx = vsf.Context(_params(vsf, 64, 48))
+    got = ctx.debug_lssd_inverse3(H)
+    ref = np.zeros_like(H)
+    fn = oracle.lib().orc_lssd_debug_inverse3
+    for i in range(len(H)):
+        fn(H[i].ctypes.data_as(C.c_void_p), ref[i].ctypes.data_as(C.c_void_p))
+    same = got.view(np.uint32) == ref.view(np.uint32)
+    both_nan = np.isnan(got) & np.isnan(ref)
+    assert (same | both_nan).all()
+    d = np.abs(np.diagonal(H, axis1=1, axis2=2))
+    assert len({int(k) for k in d[:2100].argmax(1)}) == 3     # every first pivot occurs
+    ctx.close()
+
+
 def test_caller_rewrites_table_between_calls(vsf, oracle, synth):
     """The tracker's own id -> translation map (transform_): rewritten positions of surviving ids are
     ignored, new ids start from the table, and a reordered table is matched by id."""

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "vsf_batch_upload", "vsf_batch_download", "vsf_batch_device_tables", "vsf_batch_status",
     "vsf_batch_export_tracks",
     "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig", "vsf_debug_anms",
-    "vsf_batch_frontend_post_track", "vsf_unproject", "vsf_debug_lssd", "vsf_debug_lssd_pyramid",
+    "vsf_batch_frontend_post_track", "vsf_unproject", "vsf_debug_lssd", "vsf_debug_lssd_pyramid", "vsf_debug_lssd_inverse3",
     "vsf_profile_enable", "vsf_profile_read",
 ]
 
@@ -300,6 +300,12 @@ class Context:
         ok = np.zeros(len(pts), np.uint8)
         self._chk(lib().vsf_debug_lssd(self._h, _vp(prev), _vp(nxt), w, h, _vp(pts), _vp(out), _vp(ok), len(pts)))
         return out, ok
+
+    def debug_lssd_inverse3(self, H):
+        H = np.ascontiguousarray(H, np.float32).reshape(-1, 3, 3)
+        out = np.zeros_like(H)
+        self._chk(lib().vsf_debug_lssd_inverse3(self._h, _vp(H), _vp(out), len(H)))
+        return out
 
     def debug_lssd_pyramid(self, img):
         img = np.ascontiguousarray(img, np.uint8)

@@ -1328,6 +1328,25 @@ int vsf_debug_lssd(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t
   return rc;
 }
 
+int vsf_debug_lssd_inverse3(vsf_ctx* c, const float* H, float* Hinv, int32_t n) {
+  if (!c || n < 0 || (n > 0 && (!H || !Hinv))) return VSF_E_INVALID;
+  if (n == 0) return VSF_OK;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  float *d_in = nullptr, *d_out = nullptr;
+  int rc = dalloc(c, &d_in, (size_t)n * 9);
+  if (!rc) rc = dalloc(c, &d_out, (size_t)n * 9);
+  if (!rc && hipMemcpy(d_in, H, (size_t)n * 36, hipMemcpyHostToDevice) != hipSuccess) rc = VSF_E_HIP;
+  if (!rc) {
+    hipLaunchKernelGGL(lssd_inverse3_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, d_in, d_out, n);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) rc = VSF_E_HIP;
+  }
+  if (!rc && hipMemcpy(Hinv, d_out, (size_t)n * 36, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (rc == VSF_E_HIP) return fail(c, rc, "vsf_debug_lssd_inverse3: HIP failure");
+  return rc;
+}
+
 int vsf_debug_lssd_pyramid(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t level,
                            uint16_t* out) {
   if (!c || !img || !out) return VSF_E_INVALID;

@@ -169,94 +169,93 @@ __device__ __forceinline__ void lssd_sincos(float t, float& s, float& c) {  // o
   c = 1.f + t2 * (-0.5f + t2 * (1.f / 24.f + t2 * (-1.f / 720.f + t2 * (1.f / 40320.f + t2 * (-1.f / 3628800.f)))));
 }
 
-// Eigen::LDLT<Matrix3f> compute + solveInPlace(Identity), as restated in oracle lssd_ldlt_inverse3
+// Eigen::LDLT<Matrix3f> compute + solveInPlace(Identity), the arithmetic of oracle lssd_ldlt_inverse3 without
+// its dynamically indexed arrays (which cost ~200 select instructions per call here).
+//   * The in-place factorisation touches the lower triangle only; with the pivot of step 0 in {0,1,2} and of
+//     step 1 in {1,2} the symmetric swaps are fixed register exchanges under two small branches.
+//   * solve(Identity) is P^T (L D L^T)^-1 P column by column.  A column of P is a unit vector, and running
+//     the substitutions on unit vector e_r performs exactly the operations the oracle performs on the column of
+//     P that equals e_r, so W = (L D L^T)^-1 is formed once on e_0, e_1, e_2 and the result is the symmetric
+//     re-indexing Hinv[i][c] = W[rho(i)][rho(c)], rho = inverse of the pivot permutation.
+__device__ __forceinline__ float lssd_sel3(int i, float a, float b, float c) { return i == 0 ? a : (i == 1 ? b : c); }
+
 __device__ inline void lssd_ldlt_inverse3(const float (&H)[3][3], float (&Hinv)[3][3]) {
-  float m[3][3];
-  int tr[3];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) m[i][j] = H[i][j];
-  for (int k = 0; k < 3; k++) {
-    int big = k;
-    float bv = fabsf(m[k][k]);
-    for (int i = k + 1; i < 3; i++)
-      if (fabsf(m[i][i]) > bv) {
-        bv = fabsf(m[i][i]);
-        big = i;
-      }
-    tr[k] = big;
-    if (big != k) {
-      const int s = 3 - big - 1;
-      for (int j = 0; j < k; j++) {
-        const float t = m[k][j];
-        m[k][j] = m[big][j];
-        m[big][j] = t;
-      }
-      for (int i = 0; i < s; i++) {
-        const float t = m[big + 1 + i][k];
-        m[big + 1 + i][k] = m[big + 1 + i][big];
-        m[big + 1 + i][big] = t;
-      }
-      {
-        const float t = m[k][k];
-        m[k][k] = m[big][big];
-        m[big][big] = t;
-      }
-      for (int i = k + 1; i < big; i++) {
-        const float t = m[i][k];
-        m[i][k] = m[big][i];
-        m[big][i] = t;
-      }
-    }
-    const int rs = 3 - k - 1;
-    if (k > 0) {
-      float temp[3] = {0.f, 0.f, 0.f};
-      for (int j = 0; j < k; j++) temp[j] = m[j][j] * m[k][j];
-      float dot = 0.f;
-      for (int j = 0; j < k; j++) dot = (j == 0) ? m[k][j] * temp[j] : dot + m[k][j] * temp[j];
-      m[k][k] -= dot;
-      for (int i = 0; i < rs; i++) {
-        float d2 = 0.f;
-        for (int j = 0; j < k; j++) d2 = (j == 0) ? m[k + 1 + i][j] * temp[j] : d2 + m[k + 1 + i][j] * temp[j];
-        m[k + 1 + i][k] -= d2;
-      }
-    }
-    const float akk = m[k][k];
-    if (rs > 0 && fabsf(akk) > 0.f)
-      for (int i = 0; i < rs; i++) m[k + 1 + i][k] /= akk;
+  float a00 = H[0][0], a10 = H[1][0], a11 = H[1][1], a20 = H[2][0], a21 = H[2][1], a22 = H[2][2];
+  auto swp = [](float& x, float& y) {
+    const float t = x;
+    x = y;
+    y = t;
+  };
+  // k = 0: largest |diagonal| (first one wins ties)
+  int t0 = 0;
+  float bv = fabsf(a00);
+  if (fabsf(a11) > bv) {
+    bv = fabsf(a11);
+    t0 = 1;
   }
-  float X[3][3];
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) X[i][j] = (i == j) ? 1.f : 0.f;
-  for (int k = 0; k < 3; k++)
-    if (tr[k] != k)
-      for (int j = 0; j < 3; j++) {
-        const float t = X[k][j];
-        X[k][j] = X[tr[k]][j];
-        X[tr[k]][j] = t;
-      }
-  for (int c = 0; c < 3; c++)
-    for (int i = 1; i < 3; i++)
-      for (int j = 0; j < i; j++) X[i][c] -= m[i][j] * X[j][c];
+  if (fabsf(a22) > bv) t0 = 2;
+  if (t0 == 1) {
+    swp(a20, a21);
+    swp(a00, a11);
+  } else if (t0 == 2) {
+    swp(a00, a22);
+    swp(a10, a21);
+  }
+  if (fabsf(a00) > 0.f) {
+    a10 /= a00;
+    a20 /= a00;
+  }
+  // k = 1: the remaining diagonal entries are compared as they stand (left-looking update)
+  const int t1 = fabsf(a22) > fabsf(a11) ? 2 : 1;
+  if (t1 == 2) {
+    swp(a10, a20);
+    swp(a11, a22);
+  }
+  {
+    const float temp0 = a00 * a10;
+    a11 -= a10 * temp0;
+    a21 -= a20 * temp0;
+    if (fabsf(a11) > 0.f) a21 /= a11;
+  }
+  // k = 2
+  {
+    const float temp0 = a00 * a20, temp1 = a11 * a21;
+    a22 -= a20 * temp0 + a21 * temp1;
+  }
+  // W = (L D L^T)^-1 on the unit vectors
   const float tol = 1.f / 3.4028234663852886e+38f;
+  const float d[3] = {a00, a11, a22};
+  float W[3][3];
+#pragma unroll
+  for (int r = 0; r < 3; r++) {
+    float x[3] = {r == 0 ? 1.f : 0.f, r == 1 ? 1.f : 0.f, r == 2 ? 1.f : 0.f};
+    // run-time values to the optimiser, as the entries of P are in the oracle: folding 0 - a * 1 into -a
+    // would turn +0 into -0 on exactly diagonal matrices
+    asm volatile("" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+    x[1] -= a10 * x[0];
+    x[2] -= a20 * x[0];
+    x[2] -= a21 * x[1];
+#pragma unroll
+    for (int i = 0; i < 3; i++) x[i] = fabsf(d[i]) > tol ? x[i] / d[i] : 0.f;
+    x[1] -= a21 * x[2];
+    x[0] -= a10 * x[1];
+    x[0] -= a20 * x[2];
+    W[0][r] = x[0];
+    W[1][r] = x[1];
+    W[2][r] = x[2];
+  }
+  // rho for (t0, t1) = (0,1) (0,2) (1,1) (1,2) (2,1) (2,2): two bits per case
+  const int code = 2 * (2 * t0 + (t1 - 1));
+  const int rho[3] = {(0x690 >> code) & 3, (0x909 >> code) & 3, (0x066 >> code) & 3};
+  float Tm[3][3];
+#pragma unroll
   for (int i = 0; i < 3; i++)
-    for (int c = 0; c < 3; c++) {
-      if (fabsf(m[i][i]) > tol)
-        X[i][c] /= m[i][i];
-      else
-        X[i][c] = 0.f;
-    }
-  for (int c = 0; c < 3; c++)
-    for (int i = 1; i >= 0; i--)
-      for (int j = i + 1; j < 3; j++) X[i][c] -= m[j][i] * X[j][c];
-  for (int k = 2; k >= 0; k--)
-    if (tr[k] != k)
-      for (int j = 0; j < 3; j++) {
-        const float t = X[k][j];
-        X[k][j] = X[tr[k]][j];
-        X[tr[k]][j] = t;
-      }
+#pragma unroll
+    for (int c = 0; c < 3; c++) Tm[i][c] = lssd_sel3(rho[i], W[0][c], W[1][c], W[2][c]);
+#pragma unroll
   for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) Hinv[i][j] = X[i][j];
+#pragma unroll
+    for (int c = 0; c < 3; c++) Hinv[i][c] = lssd_sel3(rho[c], Tm[i][0], Tm[i][1], Tm[i][2]);
 }
 
 // One pyramid level of TrackPoint for the feature of this half-wavefront: the patch of the old image
@@ -488,6 +487,18 @@ __global__ void lssd_snapshot_kernel(const uint64_t* __restrict__ ids, const dou
     st_xy[sb + f] = make_float2((float)p.x, (float)p.y);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) st_n[stream] = nf;
+}
+
+// lssd_ldlt_inverse3 on n matrices (row-major 3x3), for parity tests of every pivot order
+__global__ void lssd_inverse3_kernel(const float* __restrict__ H, float* __restrict__ Hinv, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float h[3][3], o[3][3];
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) h[r][c] = H[9 * i + 3 * r + c];
+  lssd_ldlt_inverse3(h, o);
+  for (int r = 0; r < 3; r++)
+    for (int c = 0; c < 3; c++) Hinv[9 * i + 3 * r + c] = o[r][c];
 }
 
 // TrackPoint (forward only) on a point list, for parity tests
