@@ -209,8 +209,8 @@ int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStr
     const bool aligned = ((uintptr_t)src % 4 == 0) && sst % 4 == 0 && sp % 4 == 0 && c->lw[l - 1] % 4 == 0 &&
                          c->lw[l - 1] >= 8 && ((uintptr_t)ps.lv[l] % 4 == 0) && dst_sst % 4 == 0 && c->lp[l] % 4 == 0;
     if (aligned)
-      hipLaunchKernelGGL(pyr_down_dword_kernel, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
-                         ps.lv[l], dst_sst, c->lp[l], c->lw[l], c->lh[l]);
+      hipLaunchKernelGGL(pyr_down_dword_kernel<false>, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
+                         (void*)ps.lv[l], dst_sst, c->lp[l], c->lw[l], c->lh[l]);
     else
       hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
                          ps.lv[l], dst_sst, c->lp[l], c->lw[l], c->lh[l]);
@@ -282,7 +282,14 @@ int lssd_build_pyramid(vsf_ctx* c, const FrameRef& f, uint16_t* const* lv, int s
     const int dw = c->l16w[l], dh = c->l16h[l];
     if (dw <= 0 || dh <= 0) continue;
     dim3 grid((dw + PD_TW - 1) / PD_TW, (dh + PD_TH - 1) / PD_TH, streams);
-    if (l == 1)
+    // level 1 from a 4-byte aligned u8 frame of even width: the dword pyrDown kernel, unrounded (see its comment).
+    // basalt's level is (w >> 1) wide, cv's is (w + 1) >> 1: the same for even w, and then the right border
+    // (column w -> w - 2) is the same reflection too.
+    if (l == 1 && ((uintptr_t)f.ptr % 4 == 0) && f.sstride % 4 == 0 && f.pitch % 4 == 0 && c->l16w[0] % 4 == 0 &&
+        c->l16w[0] >= 8 && ((uintptr_t)lv[1] % 8 == 0) && ((long long)dw * dh) % 4 == 0)
+      hipLaunchKernelGGL(pyr_down_dword_kernel<true>, grid, dim3(256), 0, s, f.ptr, f.sstride, f.pitch, c->l16w[0],
+                         c->l16h[0], (void*)lv[1], (long long)dw * dh, dw, dw, dh);
+    else if (l == 1)
       hipLaunchKernelGGL(lssd_subsample_kernel<true>, grid, dim3(256), 0, s, f.ptr, f.sstride, f.pitch, c->l16w[0],
                          c->l16h[0], lv[1], dw, dh);
     else

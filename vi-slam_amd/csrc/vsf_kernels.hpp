@@ -114,16 +114,19 @@ __global__ __launch_bounds__(256) void pyr_down_kernel(const uint8_t* __restrict
 //            32-bit integer (the sum is <= 65280 + 128, no carry into the upper half) and written as one dword.
 constexpr int PD_SD = 34;  // dwords per staged row
 
+// OUT16: the destination is a dense u16 level holding the UNROUNDED double sum.  That is level 1 of basalt's
+// u16 mip pyramid of the frame read as v << 8 (vsf_lssd.hpp): (sum * 256 + 128) >> 8 == sum.  dst_sstride and
+// dst_pitch are then in u16 elements.
+template <bool OUT16>
 __global__ __launch_bounds__(256) void pyr_down_dword_kernel(const uint8_t* __restrict__ src, long long src_sstride,
                                                              int src_pitch, int sw, int sh,
-                                                             uint8_t* __restrict__ dst, long long dst_sstride,
+                                                             void* __restrict__ dst, long long dst_sstride,
                                                              int dst_pitch, int dw, int dh) {
   __shared__ uint32_t s_src[PD_SH * PD_SD];
   __shared__ uint32_t s_h[PD_SH * (PD_TW / 2 + 2)];
   constexpr int HP = PD_TW / 2 + 2;  // pitch of s_h in dwords (even: 8-byte reads stay aligned)
   const int stream = blockIdx.z;
   const uint8_t* S = src + (long long)stream * src_sstride;
-  uint8_t* D = dst + (long long)stream * dst_sstride;
   const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
   const int gx_base = 2 * ox - 4, sy0 = 2 * oy - 2;
   for (int i = threadIdx.x; i < PD_SH * PD_SD; i += 256) {
@@ -167,10 +170,23 @@ __global__ __launch_bounds__(256) void pyr_down_dword_kernel(const uint8_t* __re
       const uint32_t* c = s_h + (2 * y) * HP + 2 * q;
       uint32_t lo = c[0] + c[4 * HP] + 4 * (c[HP] + c[3 * HP]) + 6 * c[2 * HP];
       uint32_t hi = c[1] + c[4 * HP + 1] + 4 * (c[HP + 1] + c[3 * HP + 1]) + 6 * c[2 * HP + 1];
-      lo = (lo + 0x00800080u) >> 8 & 0x00ff00ffu;
-      hi = (hi + 0x00800080u) >> 8 & 0x00ff00ffu;
-      const uint32_t out = (lo & 255) | (lo >> 16 << 8) | (hi & 255) << 16 | (hi >> 16 << 24);
-      *reinterpret_cast<uint32_t*>(D + (long long)gy * dst_pitch + gx) = out;  // dst_pitch = roundup4(dw): pad bytes
+      if (OUT16) {
+        uint16_t* D = reinterpret_cast<uint16_t*>(dst) + (long long)stream * dst_sstride + (long long)gy * dst_pitch + gx;
+        if ((dst_pitch & 3) == 0) {  // gx is a multiple of 4 and < dw: the four outputs exist, 8-byte aligned
+          *reinterpret_cast<uint2*>(D) = make_uint2(lo, hi);
+        } else {
+          D[0] = (uint16_t)lo;
+          if (gx + 1 < dw) D[1] = (uint16_t)(lo >> 16);
+          if (gx + 2 < dw) D[2] = (uint16_t)hi;
+          if (gx + 3 < dw) D[3] = (uint16_t)(hi >> 16);
+        }
+      } else {
+        uint8_t* D = reinterpret_cast<uint8_t*>(dst) + (long long)stream * dst_sstride;
+        lo = (lo + 0x00800080u) >> 8 & 0x00ff00ffu;
+        hi = (hi + 0x00800080u) >> 8 & 0x00ff00ffu;
+        const uint32_t out = (lo & 255) | (lo >> 16 << 8) | (hi & 255) << 16 | (hi >> 16 << 24);
+        *reinterpret_cast<uint32_t*>(D + (long long)gy * dst_pitch + gx) = out;  // dst_pitch = roundup4(dw): pad bytes
+      }
     }
   }
 }
