@@ -749,7 +749,22 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     delete c;
     return VSF_E_INVALID;
   }
-  c->cand_cap = 2048;
+  // Candidate slots per cell = LDS-resident keys of select_kernel.  Strict 3x3 local maxima above the
+  // quality threshold are a small fraction of a cell; a sixth of its pixels covers textured content with
+  // margin (beyond it select_kernel falls back to re-deriving candidates from the lambda map: exact, but two
+  // orders of magnitude slower -- with the former fixed 2048 the 320x180 cells of C3 hit that every frame).
+  {
+    long long want = ((long long)c->max_cw * c->max_ch / 6 + 255) & ~255LL;
+    const long long lds_room = (150 * 1024 - (long long)(c->grid_max > 0 ? c->grid_max : 1) * 12) / 8;
+    if (want < 2048) want = 2048;
+    if (want > 16384) want = 16384;
+    if (want > lds_room) want = lds_room & ~255LL;
+    if (const char* e = getenv("VSF_DEBUG_CAND_CAP")) {  // test hook: force the overflow path of select_kernel
+      const long long v = atoll(e);
+      if (v >= 16 && v < want) want = v;
+    }
+    c->cand_cap = (int)want;
+  }
   c->hash_size = 64;
   while (c->hash_size < 2 * c->cap) c->hash_size <<= 1;
   if ((size_t)(c->hash_size + c->ncell) * 4 > 150 * 1024) {
