@@ -11,10 +11,14 @@ for name, (w, h, levels, maxn, grid, B) in {"C3": (1280, 720, 4, 1000, (4, 4), 2
     bench.W, bench.H = w, h
     frames = bench.synth_frames(B, 4, dev, 0)
     torch.cuda.synchronize()
-    for tracker in ("lk", "lssd"):
+    for tracker in ("lk", "lssd", "lk+anms"):
+        if tracker == "lk+anms" and 2 * maxn > 2048:
+            continue  # anms_detection_features <= 2048
         p = vsf.default_params(grid_rows=grid[0], grid_cols=grid[1], max_features=maxn, min_distance=10.0, klt_win=21,
                                klt_max_level=levels - 1, width=w, height=h, streams=B,
-                               tracker_kind=vsf.TRACKER_LSSD if tracker == "lssd" else vsf.TRACKER_LK)
+                               tracker_kind=vsf.TRACKER_LSSD if tracker == "lssd" else vsf.TRACKER_LK,
+                               detector_kind=vsf.DETECTOR_ANMS if tracker.endswith("anms") else vsf.DETECTOR_BUCKETING,
+                               anms_detection_features=2 * maxn if tracker.endswith("anms") else 600)
         ctx = vsf.Context(p)
         order = [0, 1, 2, 3, 2, 1]
         fs = w * h
