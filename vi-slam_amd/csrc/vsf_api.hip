@@ -394,7 +394,7 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
     ProfScope prof(c, VSF_K_CANDIDATES, s);
     hipLaunchKernelGGL(candidate_kernel, dim3(tiles_x * tiles_y, c->ncell, streams), dim3(256), 0, s, c->d_lam, G,
                        c->d_nact, tiles_x, c->d_cellmax, c->p.quality_level, masks, mask_sstride, mask_pitch,
-                       c->d_cand, c->cand_cap, c->d_candcnt);
+                       c->d_cand, c->cand_cap, c->d_candcnt, 0);
   }
   {
     ProfScope prof(c, VSF_K_SELECT, s);
@@ -457,8 +457,8 @@ int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long l
   }
   {
     ProfScope prof(c, VSF_K_CANDIDATES, s);
-    hipLaunchKernelGGL(candidate_kernel, dim3(tiles_x * tiles_y, 1, streams), dim3(256), 0, s, c->d_lam, G, c->d_anact,
-                       tiles_x, c->d_cellmax, ap.quality, c->d_aflag, fsz, W, c->d_acand, ap.cand_cap, c->d_candcnt);
+    hipLaunchKernelGGL(candidate_kernel, dim3(streams, 1, tiles_x * tiles_y), dim3(256), 0, s, c->d_lam, G, c->d_anact,
+                       tiles_x, c->d_cellmax, ap.quality, c->d_aflag, fsz, W, c->d_acand, ap.cand_cap, c->d_candcnt, 1);
   }
   {
     ProfScope prof(c, VSF_K_SELECT, s);
