@@ -278,6 +278,27 @@ __device__ __forceinline__ int to_sgpr(float v) {
   return s;
 }
 
+// Several lane reads behind ONE pair of wait states (the leading one covers the first read, the later reads
+// are further away from their producers; the trailing two cover the last SGPR written).
+__device__ __forceinline__ void to_sgpr3(float a, float b, float c, int& sa, int& sb, int& sc) {
+  asm volatile(
+      "s_nop 0\n\tv_readfirstlane_b32 %0, %3\n\tv_readfirstlane_b32 %1, %4\n\tv_readfirstlane_b32 %2, %5\n\ts_nop 1"
+      : "=&s"(sa), "=&s"(sb), "=&s"(sc)
+      : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void to_sgpr2(int a, int b, int& sa, int& sb) {
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 1"
+               : "=&s"(sa), "=&s"(sb)
+               : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void to_sgpr4(int a, int b, int c, int d, int& sa, int& sb, int& sc, int& sd) {
+  asm volatile(
+      "s_nop 0\n\tv_readfirstlane_b32 %0, %4\n\tv_readfirstlane_b32 %1, %5\n\tv_readfirstlane_b32 %2, %6\n\t"
+      "v_readfirstlane_b32 %3, %7\n\ts_nop 1"
+      : "=&s"(sa), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+      : "v"(a), "v"(b), "v"(c), "v"(d));
+}
+
 // The same sums through the LDS ATOMIC unit.  The kernel is VALU-issue bound while the LDS pipe idles, so
 // only the first NRAW butterfly steps run as DPP adds (the values still fit int32: NRAW = 3 needs
 // |p| < 2^28, NRAW = 2 needs |p| < 2^29); then one lane of every 2^NRAW adds its partial sum as a
@@ -339,11 +360,19 @@ __device__ __forceinline__ void wave_sums_exact_lds(const int (&p)[N], float (&o
         : "v"(a32)
         : "memory");
   }
+  int los[N], his[N];
+  if constexpr (N == 2) {
+    to_sgpr4((int)(unsigned int)(unsigned long long)t[0], (int)(t[0] >> 32), (int)(unsigned int)(unsigned long long)t[1],
+             (int)(t[1] >> 32), los[0], his[0], los[1], his[1]);
+  } else {
+    to_sgpr4((int)(unsigned int)(unsigned long long)t[0], (int)(t[0] >> 32), (int)(unsigned int)(unsigned long long)t[1],
+             (int)(t[1] >> 32), los[0], his[0], los[1], his[1]);
+    to_sgpr2((int)(unsigned int)(unsigned long long)t[N - 1], (int)(t[N - 1] >> 32), los[N - 1], his[N - 1]);
+  }
 #pragma unroll
   for (int i = 0; i < N; i++) {
     // scalar from here on: the range test and the recombination cost no vector instruction
-    const int lo = to_sgpr((int)(unsigned int)(unsigned long long)t[i]);
-    const int hi = to_sgpr((int)(t[i] >> 32));
+    const int lo = los[i], hi = his[i];
     if (hi == (lo >> 31))
       out[i] = (float)lo;
     else
@@ -359,9 +388,11 @@ __device__ __forceinline__ void bilinear_weights_uniform(float a, float b, int& 
   const float MAGIC = 12582912.f;  // 1.5 * 2^23
   const float a1 = 1.f - a;
   const float b1 = (1.f - b) * (float)(1 << W_BITS), b0 = b * (float)(1 << W_BITS);
-  w00 = to_sgpr(a1 * b1 + MAGIC) - 0x4B400000;
-  w01 = to_sgpr(a * b1 + MAGIC) - 0x4B400000;
-  w10 = to_sgpr(a1 * b0 + MAGIC) - 0x4B400000;
+  int s00, s01, s10;
+  to_sgpr3(a1 * b1 + MAGIC, a * b1 + MAGIC, a1 * b0 + MAGIC, s00, s01, s10);
+  w00 = s00 - 0x4B400000;
+  w01 = s01 - 0x4B400000;
+  w10 = s10 - 0x4B400000;
   w11 = (1 << W_BITS) - w00 - w01 - w10;
 }
 
