@@ -17,7 +17,7 @@
 #include <type_traits>
 
 #ifndef VSF_LK_WAVES
-#define VSF_LK_WAVES 5  // waves per SIMD the LK kernels are register-limited to (window <= 21)
+#define VSF_LK_WAVES 7  // waves per SIMD the LK kernels are register-limited to (window <= 21): 72 registers
 #endif
 #ifndef VSF_SUM_LDS
 #define VSF_SUM_LDS 1  // exact sums through the LDS atomic unit (0: DPP + v_readlane only)
@@ -511,6 +511,7 @@ struct LkSmem {
   RegionGeom gi;  // template patch of I: (win+3) rows, covers win+3 columns at any 4-byte phase
   RegionGeom gj;  // J region: window + margin
   int d_pitch;    // gradient patch (win+1)^2, packed (Ix | Iy<<16) int32 (generic path only)
+  int jp_pitch;   // J region in PAIR layout: dwords per row (4 * gj.ndw pairs + 2 of padding)
   int off_j, off_d;
   int off_acc;   // 4 x int64 accumulators of the exact sums
   int off_mask;  // per lane: NP dwords, 16-bit masks of the window pixels the lane owns (pair-packed)
@@ -541,11 +542,19 @@ __host__ __device__ inline LkSmem lk_smem_layout(int win, int jmargin) {
   s.d_pitch = win + 1;
   const int si = s.gi.pitch * s.gi.rows + 32;  // +slack: dword-granular readers may run past a row end
   s.off_j = (si + 15) & ~15;
-  s.off_d = s.off_j + ((s.gj.pitch * s.gj.rows + 32 + 15) & ~15);
-  s.off_acc = s.off_d + ((s.d_pitch * (win + 1) * 4 + 15) & ~15);
+  // The J region is kept as pixel PAIRS, one dword per pixel: byte(x) | byte(x + 1) << 16, the operand v_dot2
+  // takes, so the iterations spend no v_perm / v_alignbyte on it.  The gradient patch of the border path (sD)
+  // is dead before the first J staging of a level and shares the space.
+  s.jp_pitch = 4 * s.gj.ndw + 2;
+  const int sj = s.jp_pitch * 4 * s.gj.rows + 64, sd = s.d_pitch * (win + 1) * 4;
+  s.off_d = s.off_j;
+  s.off_acc = s.off_j + (((sj > sd ? sj : sd) + 15) & ~15);
   s.off_mask = s.off_acc + 32;
   const int np = (lk_seg_template(lk_seglen(win)) + 1) / 2;
   s.total = s.off_mask + 64 * 4 * np;
+#ifdef VSF_LDS_PAD  // occupancy experiments
+  s.total += VSF_LDS_PAD;
+#endif
   return s;
 }
 
@@ -611,6 +620,58 @@ __device__ __forceinline__ void region_stage_slow(uint8_t* dst, const uint8_t* _
   }
 }
 
+// ---- pair layout (J region): LDS dword (row, x) = byte(x) | byte(x + 1) << 16
+__device__ __forceinline__ void pairs_of_dword(unsigned int d0, unsigned int d1, unsigned int (&P)[4]) {
+  P[0] = __builtin_amdgcn_perm(0u, d0, 0x0c010c00u);
+  P[1] = __builtin_amdgcn_perm(0u, d0, 0x0c020c01u);
+  P[2] = __builtin_amdgcn_perm(0u, d0, 0x0c030c02u);
+  P[3] = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u);
+}
+
+// Registers of region_load_regs -> pair layout.  The dword to the right is the next lane's (the staging map puts
+// consecutive columns on consecutive lanes of a 16-lane DPP row); the last column's fourth pair would need a
+// byte outside the region and is never read (the iterations restage before the window reaches it).
+template <int N>
+__device__ __forceinline__ void region_store_pairs(unsigned int* dst, const unsigned int (&reg)[N], const RegionGeom& g,
+                                                   int pitch_dw, int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  const int off = yl * pitch_dw + 4 * xd, step = ystep * pitch_dw;
+  const bool xin = xd < g.ndw;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const unsigned int right = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)reg[i], 0x101, 0xf, 0xf, true);  // row_shl:1
+    unsigned int P[4];
+    pairs_of_dword(reg[i], right, P);
+    if (xin && yl + i * ystep < g.rows) {
+      unsigned int* d = dst + off + i * step;
+      d[0] = P[0];
+      d[1] = P[1];
+      d[2] = P[2];
+      d[3] = P[3];
+    }
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void region_stage_slow_pairs(unsigned int* dst, const uint8_t* __restrict__ src, int sp,
+                                                        int sw, int sh, int xa, int y0, const RegionGeom& g,
+                                                        int pitch_dw, int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  if (xd < g.ndw) {
+    for (int y = yl; y < g.rows; y += ystep) {
+      const uint8_t* sr = src + (long long)reflect101(y0 + y, sh) * sp;
+      unsigned int b[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) b[k] = (unsigned int)sr[reflect101(xa + 4 * xd + k, sw)];
+      unsigned int* d = dst + y * pitch_dw + 4 * xd;
+#pragma unroll
+      for (int k = 0; k < 4; k++) d[k] = b[k] | (b[k + 1] << 16);
+    }
+  }
+}
+
 // Tracks one point from pyramid A (template, derivatives) to pyramid B.  Wave-uniform control flow.
 // Returns the OpenCV status (true = found); out = nextPts.
 // SEG = compile-time pixels per lane (>= prm.seglen).  Gradients are held pair-packed
@@ -627,7 +688,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
   const int lane0 = threadIdx.x & 63;
   const int win = prm.win;
   uint8_t* sI = smem;
-  uint8_t* sJ = smem + L.off_j;
+  unsigned int* sJ = reinterpret_cast<unsigned int*>(smem + L.off_j);
   int* sD = reinterpret_cast<int*>(smem + L.off_d);
   long long* sAcc = reinterpret_cast<long long*>(smem + L.off_acc);
   const float half = (float)(win - 1) * 0.5f;
@@ -651,7 +712,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     const int rr = owner ? r : 0, xx0 = owner ? x0 : 0;        // idle lanes read a valid (unused) place
     const unsigned int* sMask = reinterpret_cast<const unsigned int*>(smem + L.off_mask) + lane * NP;
     const int rowI = __mul24(rr, L.gi.pitch);
-    const uint8_t* rowJ0 = sJ + __mul24(rr, L.gj.pitch) + xx0;
+    const unsigned int* rowJ0 = sJ + __mul24(rr, L.jp_pitch) + xx0;
     const float lscale = 1.f / (float)(1 << level);
     float px = ptx * lscale, py = pty * lscale;
     if (level == maxLevel) {
@@ -878,9 +939,9 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           if (region_is_fast(Bb, bp, bw, bh, jx0, jy0, L.gj)) {
             unsigned int rj[NJ];
             region_load_regs<NJ>(rj, Bb, bp, jx0, jy0, L.gj, lane);
-            region_store_regs<NJ>(sJ, rj, L.gj, lane);
+            region_store_pairs<NJ>(sJ, rj, L.gj, L.jp_pitch, lane);
           } else {
-            region_stage_slow<NJ>(sJ, Bb, bp, bw, bh, jx0, jy0, L.gj, lane);
+            region_stage_slow_pairs<NJ>(sJ, Bb, bp, bw, bh, jx0, jy0, L.gj, L.jp_pitch, lane);
           }
           staged = true;
           __syncthreads();
@@ -889,17 +950,26 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         bilinear_weights_uniform(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
         int b1 = -cI1, b2 = -cI2;
         {
-          unsigned int R0[NA], R1[NA];
+          unsigned int R0[SEG], R1[SEG];
           // rowJ0 = sJ + rr * pitch + xx0 per lane; the rest of the address is wave-uniform
-          const uint8_t* p0 = rowJ0 + ((iny - jy0) * L.gj.pitch + (inx - jx0));
-          lds_stream_at<NA>(p0, L.gj.pitch, R0, R1);
+          const unsigned int* p0 = rowJ0 + ((iny - jy0) * L.jp_pitch + (inx - jx0));
+#pragma unroll
+          for (int k = 0; k < SEG; k++) R0[k] = p0[k];
+#pragma unroll
+          for (int k = 0; k < SEG; k++) R1[k] = p0[L.jp_pitch + k];
           const unsigned int V0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
           const unsigned int V1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
           int Jw[SEG + 1];
           Jw[SEG] = 0;
           {
             int Jr[SEG];
-            bilinear_row<SEG, NA, (1 << (W_BITS - 5 - 1))>(iw11 >= 0, R0, R1, V0, V1, Jr);
+            if (iw11 >= 0) {
+#pragma unroll
+              for (int k = 0; k < SEG; k++) Jr[k] = udot2(R1[k], V1, udot2(R0[k], V0, (1 << (W_BITS - 5 - 1))));
+            } else {
+#pragma unroll
+              for (int k = 0; k < SEG; k++) Jr[k] = sdot2(R1[k], V1, sdot2(R0[k], V0, (1 << (W_BITS - 5 - 1))));
+            }
 #pragma unroll
             for (int k = 0; k < SEG; k++) Jw[k] = Jr[k] >> (W_BITS - 5);  // 0 <= Jw <= 8160
           }
