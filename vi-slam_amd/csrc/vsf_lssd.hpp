@@ -3,7 +3,7 @@
 // patch.h, patterns.h): basalt's frame-to-frame SE(2) patch tracker with Pattern24, float arithmetic,
 // forward + backward tracking and the recovered-distance test.
 // One 32-lane half-wavefront per feature, lane i = pattern point i (24 of 32 lanes carry a point).
-// Every sum over the pattern is a 32-slot butterfly (xor 1, 2, 4, 8, 16) -- the order the oracle's
+// Every sum over the pattern is a 32-slot butterfly (xor 1, 2, 4, 8, 16; DPP and permlane moves) -- the order the oracle's
 // ORC_LSSD_TREE mode uses -- and every other expression is written exactly as in oracle/vsf_oracle.c,
 // so the results are equal bit for bit (the build uses -ffp-contract=off; float division and sqrt are
 // correctly rounded).  Included by vsf_kernels.hpp.
@@ -138,7 +138,6 @@ __device__ __forceinline__ void lssd_interp_grad(const Lvl16& im, float x, float
   out[2] = 0.5f * (res_py - res_my);
 }
 
-// 32-slot butterfly sum: every lane of the half-wavefront ends with the same value
 // Butterfly sum over a 32-lane half, every lane of the half gets the total.  The partner of step k is lane i ^ k;
 // after the steps 1 and 2 a quad is uniform, so lane i ^ 7 (row_half_mirror) holds what lane i ^ 4 holds, and
 // lane i ^ 15 (row_mirror) what lane i ^ 8 holds; the last step adds the two 16-lane rows of the half (float
