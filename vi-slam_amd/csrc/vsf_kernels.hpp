@@ -1447,6 +1447,17 @@ __global__ __launch_bounds__(256) void candidate_kernel(const float* __restrict_
   __shared__ unsigned long long s_keys[LCAP];
   __shared__ int s_n, s_base;
   if (threadIdx.x == 0) s_n = 0;
+  // the mask bytes of this thread's four pixels, fetched up front together with the lambda tile: read inside
+  // the survivor branch they are four dependent global round trips per thread
+  unsigned int mk[SC_TH * SC_TW / 256];
+#pragma unroll
+  for (int k = 0; k < SC_TH * SC_TW / 256; k++) {
+    const int i = threadIdx.x + 256 * k;
+    const int y = i / SC_TW, x = i - y * SC_TW;
+    const int cx = cx0 + x, cy = cy0 + y;
+    mk[k] = 1u;
+    if (M && cx < cw && cy < ch) mk[k] = M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)];
+  }
   for (int i = threadIdx.x; i < LH * LW; i += 256) {
     const int y = i / LW, x = i - y * LW;
     const int cx = cx0 - 1 + x, cy = cy0 - 1 + y;
@@ -1458,7 +1469,9 @@ __global__ __launch_bounds__(256) void candidate_kernel(const float* __restrict_
     s_lam[i] = v;
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
+#pragma unroll
+  for (int k = 0; k < SC_TH * SC_TW / 256; k++) {
+    const int i = threadIdx.x + 256 * k;
     const int y = i / SC_TW, x = i - y * SC_TW;
     const int cx = cx0 + x, cy = cy0 + y;
     if (cx >= 1 && cx < cw - 1 && cy >= 1 && cy < ch - 1) {
@@ -1470,7 +1483,7 @@ __global__ __launch_bounds__(256) void candidate_kernel(const float* __restrict_
         for (int j = -1; j <= 1; j++)
 #pragma unroll
           for (int q = -1; q <= 1; q++) m = fmaxf(m, c[j * LW + q]);
-        if (v == m && (!M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)])) {
+        if (v == m && mk[k]) {
           const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)(cy * cw + cx);
           const int ls = atomicAdd(&s_n, 1);
           if (ls < LCAP) {
