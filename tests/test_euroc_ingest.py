@@ -238,3 +238,27 @@ def test_provider_errors(euroc, synth, tmp_path):
     assert dp.GetInput() is not None
     with pytest.raises(E):
         dp.GetInput()
+
+
+def test_png_chunking_and_size_checks(euroc, tmp_path):
+    rng = np.random.default_rng(2)
+    img = rng.integers(0, 256, (23, 31)).astype(np.uint8)
+    # IDAT split into one-byte chunks, with an empty IDAT in front: still one zlib stream
+    one = _png.encode(img, idat_split=1)
+    head = one[:33]  # signature + IHDR
+    assert np.array_equal(euroc.png_decode_gray8(head + _png._chunk(b"IDAT", b"") + one[33:]), img)
+    # stored (uncompressed) deflate blocks
+    assert np.array_equal(euroc.png_decode_gray8(_png.encode(img, level=0)), img)
+    # a file whose size differs from the one the caller expects is refused, not cropped
+    p = str(tmp_path / "x.png")
+    open(p, "wb").write(_png.encode(img))
+    out = np.zeros((23, 31), np.uint8)
+    L = euroc.io_lib()
+    assert L.vsf_png_read_gray8(p.encode(), out.ctypes.data, 31, 31, 23) == 0 and np.array_equal(out, img)
+    assert L.vsf_png_read_gray8(p.encode(), out.ctypes.data, 31, 30, 23) == euroc.IO_E_FORMAT
+    assert L.vsf_png_read_gray8(p.encode(), out.ctypes.data, 16, 31, 23) == euroc.IO_E_INVALID   # stride < width
+    assert L.vsf_png_read_gray8(b"/nonexistent/file.png", out.ctypes.data, 31, 31, 23) == euroc.IO_E_FILE
+    # strided output
+    wide = np.full((23, 40), 9, np.uint8)
+    assert L.vsf_png_read_gray8(p.encode(), wide.ctypes.data, 40, 31, 23) == 0
+    assert np.array_equal(wide[:, :31], img) and (wide[:, 31:] == 9).all()

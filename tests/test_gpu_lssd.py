@@ -255,3 +255,27 @@ def test_anms_detector_with_lssd_tracker_in_one_context(vsf, oracle, synth):
             assert got == tabs[b].as_dict(), "step %d stream %d" % (t, b)
     assert (ctx.batch_status() == 0).all()
     ctx.close()
+
+
+def test_tiny_frames_and_deep_pyramids(vsf, oracle, synth):
+    """Levels smaller than the pattern: every point is out of bounds there, the level loop ends with an invalid
+    patch, the table empties -- and nothing reads outside a level."""
+    for w, h, levels in ((40, 24, 3), (18, 18, 1), (64, 48, 5)):
+        frames, _ = synth.sequence(5, w, h, 3)
+        ctx = vsf.Context(_params(vsf, w, h, lssd_levels=levels))
+        ot = oracle.LssdTracker(0.09, levels, 5, oracle.LSSD_TREE)
+        ids, xy, age = np.zeros(ctx.capacity, np.uint64), np.zeros((ctx.capacity, 2)), np.zeros(ctx.capacity, np.uint32)
+        pts = np.array([[w / 2, h / 2], [8.0, 8.0], [w - 9.0, h - 9.0], [w / 3, h / 2]])
+        n = len(pts)
+        ids[:n], xy[:n], age[:n] = np.arange(1, n + 1), pts, 2
+        T = oracle.FeatureTable(ctx.capacity)
+        T.set(ids[:n].copy(), pts.copy(), age[:n].copy())
+        for fr in frames:
+            n, _ = ctx.track(fr, ids, xy, age, n)
+            ot.track(T, fr)
+            assert n == T.n.value and np.array_equal(xy[:n], T.xy[:n]) and np.array_equal(ids[:n], T.ids[:n])
+        got = ctx.debug_lssd_pyramid(frames[0])
+        ref = oracle.lssd_build_pyramid(frames[0], levels)
+        for l in range(1, levels + 1):
+            assert np.array_equal(got[l - 1], ref[l])
+        ctx.close()

@@ -648,7 +648,8 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   if (p->width <= 0 || p->height <= 0 || p->streams < 1 || p->streams > 65535) return VSF_E_INVALID;
   if (p->klt_win < 3 || p->klt_win > MAX_WIN || p->klt_max_level < 0 || p->klt_max_level >= MAXL)
     return VSF_E_INVALID;
-  if (p->width <= p->klt_win || p->height <= p->klt_win) return VSF_E_INVALID;
+  // the LK window must fit the frame; an LSSD context never runs the LK kernels
+  if (p->tracker_kind != VSF_TRACKER_LSSD && (p->width <= p->klt_win || p->height <= p->klt_win)) return VSF_E_INVALID;
   if (p->grid_rows < 1 || p->grid_cols < 1 || p->max_features < 0 || p->block_size != 3) return VSF_E_INVALID;
   if (!(p->min_distance >= 0.0) || !(p->quality_level >= 0.0)) return VSF_E_INVALID;
   const bool use_anms = p->detector_kind == VSF_DETECTOR_ANMS;
@@ -1154,6 +1155,8 @@ int vsf_debug_pyramid(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
 int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w, int32_t h, const float* prev_pts,
                  float* next_pts, uint8_t* status, int32_t n) {
   if (!c || !prev || !next || n < 0) return VSF_E_INVALID;
+  if (c->p.tracker_kind == VSF_TRACKER_LSSD)  // such a context is not held to the LK window / frame size rule
+    return fail(c, VSF_E_INVALID, "vsf_debug_lk: not an LK context");
   if (n == 0) return VSF_OK;
   if (!prev_pts || !next_pts || !status) return VSF_E_INVALID;
   int rc = check_geom(c, w, h, w);
