@@ -13,7 +13,11 @@ t_end = time.time() + budget
 ncase = nbad = nrej = 0
 kinds = {"lk+bucket": 0, "lssd+bucket": 0, "lk+anms": 0, "lssd+anms": 0}
 while time.time() < t_end:
-    w = int(rng.integers(64, 420)); h = int(rng.integers(48, 320))
+    small = len(sys.argv) > 3 and sys.argv[3] == "small"   # tiny frames, extreme parameters
+    if small:
+        w = int(rng.integers(24, 80)); h = int(rng.integers(24, 64))
+    else:
+        w = int(rng.integers(64, 420)); h = int(rng.integers(48, 320))
     if rng.random() < 0.3:
         w = (w // 4) * 4
     seed = int(rng.integers(0, 1 << 30))
@@ -24,7 +28,12 @@ while time.time() < t_end:
     win = int(rng.choice([5, 9, 15, 21, 25, 31])); lvl = int(rng.integers(0, 4)); it = int(rng.choice([1, 5, 30])); eps = float(rng.choice([0.01, 0.1]))
     back = float(rng.choice([0.5, 1.0, 2.0]))
     llev = int(rng.integers(0, 4)); lit = int(rng.choice([1, 5, 8])); ldist = float(rng.choice([0.04, 0.09, 1.0]))
-    if min(w, h) >> max(lvl, llev) < 16:
+    if small:
+        maxn = int(rng.choice([0, 1, 2, 7, 40])); mind = float(rng.choice([0.5, 1.0, 5.0, 30.0]))
+        win = int(rng.choice([3, 5, 9, 15, 21])); lvl = int(rng.integers(0, 6)); llev = int(rng.integers(0, 5))
+        if win >= min(w, h) or (min(w, h) >> llev) < 1:
+            continue
+    elif min(w, h) >> max(lvl, llev) < 16:
         continue
     desc = dict(kind=kind, w=w, h=h, seed=seed, nfr=nfr, maxn=maxn, mind=mind, grid=(rows, cols), lk=(it, eps, win, lvl, back), lssd=(llev, lit, ldist))
     try:
