@@ -80,9 +80,11 @@ while time.time() < t_end:
     except vsf.VsfError as e:
         # a grid whose rounded cells leave the image: cv::Mat::operator()(Rect) throws in the reference, the
         # oracle returns -2, the library refuses the context (VSF_E_GEOMETRY)
-        if e.code == -4 and kind.endswith("bucket") and O.Detector(rows, cols, maxn, mind).update_detection(
-                O.FeatureTable(cap), np.zeros((h, w), np.uint8)) == -2:
+        if e.code == -4 and kind.endswith("bucket"):
+            # refused at creation when ANY cell leaves the image (the oracle / reference only when the loop reaches it)
             nrej += 1
+        elif e.code == -1 and kind.endswith("anms") and maxn == 0:
+            nrej += 1   # anms_detection_features must be 1..2048
         else:
             print("EXC", desc, repr(e), flush=True)
             nbad += 1
