@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- frames/s of one frontend step (pyramid + KLT track fwd/bwd/verify + grid detect)
-on synthetic 752x480 frames resident in HBM, BASELINE.json config C2, one process per GPU.
+on synthetic frames resident in HBM, one process per GPU.  Default workload: BASELINE.json config C2.
 
 A "step" = vsf_batch_step over B independent streams (B frames).  N GPUs => N*B streams (weak
 scaling, no data-path collective); the only collective is the final RCCL all_gather of the packed
-track records.  Prints ONE JSON line on rank 0.
+track records.  `--gpus N` without a launcher (WORLD_SIZE unset) starts the N ranks itself, before
+anything touches the GPU; under torchrun it checks that WORLD_SIZE == N.  Rank 0 prints ONE JSON line.
 
 Extra objects on the line:
   roofline     -- dominant kernel (LK forward+backward+verify): algorithmic bytes / launch divided by
                   its average launch duration, measured with HIP events on the launch stream inside
-                  the timed region (vsf_profile_*), against 8 TB/s HBM.
+                  the timed region (vsf_profile_*), against 8 TB/s HBM; `stream_copy_GBps` is a device
+                  copy measured in the same job, beside the vendor peak.
   cpu_baseline -- the CPU oracle ("restated reference CPU path", kind "port") timed on this host on
-                  a bounded sample of the same workload.
+                  a bounded sample of the same workload: all cores (OpenMP over streams) and one thread.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,29 +29,38 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-W, H = 752, 480
-LEVELS = 4
-WIN = 21
-MAX_FEATURES = 300
-GRID = (4, 4)
-MIN_DIST = 10.0
 HBM_PEAK = 8.0e12
 VALU_PEAK = 256 * 4 * 2.4e9 / 2  # wave64 vector instructions per second (SIMD-32: 2 cycles each)
 
+# SURVEY.md 8(d): sizes, grids (cols x rows), feature counts and batch sizes of BASELINE.json's configs.
+# cpu = (streams, steps) of the all-cores leg and of the one-thread leg, sized for ~5-15 s each.
+CONFIGS = {
+    "C2": dict(w=752, h=480, levels=4, win=21, rows=4, cols=4, maxn=300, mind=10.0, streams=1024,
+               cpu=((64, 100), (8, 40)), name="C2: synthetic 752x480 8-bit frames"),
+    "C3": dict(w=1280, h=720, levels=4, win=21, rows=5, cols=8, maxn=1000, mind=8.0, streams=256,
+               cpu=((32, 40), (4, 16)), name="C3: synthetic 1280x720 8-bit frames"),
+    "C4": dict(w=3840, h=2160, levels=5, win=21, rows=10, cols=16, maxn=4000, mind=12.0, streams=32,
+               cpu=((16, 8), (2, 4)), name="C4: synthetic 3840x2160 8-bit frames"),
+    "C5": dict(w=752, h=480, levels=4, win=21, rows=4, cols=4, maxn=300, mind=10.0, streams=8,
+               cpu=((8, 200), (2, 60)), name="C5: 64 independent 752x480 sequences over 8 GPUs = 8 streams per GPU"),
+}
+
 
 def pyramid_bytes(w, h, levels):
-    tot, sizes = 0, []
+    tot = 0
     for _ in range(levels):
-        sizes.append(w * h)
         tot += w * h
         w, h = (w + 1) // 2, (h + 1) // 2
-    return tot, sizes
+    return tot
 
 
-def synth_frames(B, T, device, seed):
+def synth_frames(B, T, W, H, device, seed, occlusion):
     """[T][B][H][W] uint8: per stream a random blob texture under smooth sub-pixel translation and
     small rotation, plus +-2 grey levels of noise (same recipe as vi-slam_amd/synth.py, rendered on
-    the device with torch so that thousands of distinct frames exist in HBM before timing)."""
+    the device with torch so that thousands of distinct frames exist in HBM before timing).
+    `occlusion` > 0 pastes independently placed 32x32 blocks of a foreign texture over that fraction of
+    every frame (moving occluders): the features under them fail the forward-backward check, so every
+    step loses a few per cent of its tracks and the detector has real work in (nearly) every cell."""
     import torch.nn.functional as F
     g = torch.Generator(device=device)
     g.manual_seed(0xC0FFEE + seed)
@@ -60,23 +73,27 @@ def synth_frames(B, T, device, seed):
         k = torch.exp(-x * x / (2 * sigma * sigma))
         return (k / k.sum()), r
 
-    chunk = 32
-    for b0 in range(0, B, chunk):
-        nb = min(chunk, B - b0)
-        scene = torch.zeros((nb, 1, H + 2 * M, W + 2 * M), device=device)
+    def texture(nb, hh, ww):
+        scene = torch.zeros((nb, 1, hh, ww), device=device)
         for sigma, amp in ((1.6, 420.0), (3.5, 600.0), (7.0, 500.0)):
-            noise = torch.randn((nb, 1, H + 2 * M, W + 2 * M), device=device, generator=g)
+            noise = torch.randn((nb, 1, hh, ww), device=device, generator=g)
             k, r = gauss_kernel(sigma)
             noise = F.conv2d(F.pad(noise, (r, r, 0, 0), mode="reflect"), k.view(1, 1, 1, -1))
             noise = F.conv2d(F.pad(noise, (0, 0, r, r), mode="reflect"), k.view(1, 1, -1, 1))
             scene += amp * noise / (1.0 + sigma)
-        scene = 128.0 + scene
+        return 128.0 + scene
+
+    chunk = max(1, min(32, (64 << 20) // (W * H)))
+    ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
+                            torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
+    cx, cy = (W - 1) * 0.5, (H - 1) * 0.5
+    for b0 in range(0, B, chunk):
+        nb = min(chunk, B - b0)
+        scene = texture(nb, H + 2 * M, W + 2 * M)
+        alt = texture(nb, H, W) if occlusion > 0 else None
         # smooth motion per stream: velocity <= 3 px/frame, <= 0.2 deg/frame
         v = (torch.rand((nb, 2), device=device, generator=g) * 2 - 1) * 2.5
         om = (torch.rand((nb,), device=device, generator=g) * 2 - 1) * 0.15
-        ys, xs = torch.meshgrid(torch.arange(H, device=device, dtype=torch.float32),
-                                torch.arange(W, device=device, dtype=torch.float32), indexing="ij")
-        cx, cy = (W - 1) * 0.5, (H - 1) * 0.5
         for t in range(T):
             th = torch.deg2rad(om * t).view(nb, 1, 1)
             c, s = torch.cos(th), torch.sin(th)
@@ -87,9 +104,63 @@ def synth_frames(B, T, device, seed):
             gy = w_ / (H + 2 * M - 1) * 2 - 1
             grid = torch.stack([gx, gy], -1)
             fr = F.grid_sample(scene, grid, mode="bilinear", padding_mode="border", align_corners=True)
+            if occlusion > 0:
+                gh, gw = (H + 31) // 32, (W + 31) // 32
+                occ = (torch.rand((nb, 1, gh, gw), device=device, generator=g) < occlusion).float()
+                occ = F.interpolate(occ, scale_factor=32, mode="nearest")[:, :, :H, :W] > 0.5
+                sh = torch.randint(0, 1 << 20, (2,), generator=g, device=device).tolist()
+                fr = torch.where(occ, torch.roll(alt, (sh[0] % H, sh[1] % W), (2, 3)), fr)
             fr = fr + torch.randint(-2, 3, fr.shape, device=device, generator=g)
             out[t, b0:b0 + nb] = fr.squeeze(1).round().clamp(0, 255).to(torch.uint8)
     return out
+
+
+def spawn_ranks(n):
+    """`--gpus N` without a launcher: N fresh processes, one per GPU, started before this process has
+    touched the GPU (device_count() does not initialise it); rank 0 prints the line."""
+    ndev = torch.cuda.device_count()
+    if ndev < n:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible\n" % (n, ndev))
+        sys.exit(2)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r
+                for q in live:  # a rank died: the others would wait for it at the next barrier
+                    q.terminate()
+    sys.exit(rc)
+
+
+def stream_copy_gbps(device):
+    """Device-to-device copy bandwidth (read + write bytes) measured in this job, beside the vendor peak."""
+    n = 1 << 30
+    a = torch.empty(n, dtype=torch.uint8, device=device)
+    b = torch.empty(n, dtype=torch.uint8, device=device)
+    a.zero_()
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * n * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -97,20 +168,28 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=1024, help="independent streams (frames per step) per GPU")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2", help="BASELINE.json workload (SURVEY 8(d))")
+    ap.add_argument("--streams", type=int, default=0, help="independent streams (frames per step) per GPU; 0 = the config's")
     ap.add_argument("--seq", type=int, default=6, help="distinct frames per stream held in HBM")
+    ap.add_argument("--occlusion", type=float, default=0.06,
+                    help="fraction of every frame covered by moving occluder blocks (0 = pure smooth motion)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--detector", choices=("bucketing", "anms"), default="bucketing",
                     help="FeatureDetectorShiTomasiBucketing (the headline configuration) or FeatureDetectorANMS")
     ap.add_argument("--tracker", choices=("lk", "lssd"), default="lk",
                     help="FeatureTrackerLucasKanade (the headline configuration) or FeatureTrackerLSSDLucasKanade")
-    ap.add_argument("--cpu-streams", type=int, default=64)
-    ap.add_argument("--cpu-steps", type=int, default=100)
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args.gpus)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d does not match WORLD_SIZE %d\n" % (args.gpus, world))
+        sys.exit(2)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -126,12 +205,14 @@ def main():
     import importlib
     mg = importlib.import_module("vi_slam_amd.multigpu")
 
-    B, T = args.streams, max(2, args.seq)
-    frames = synth_frames(B, T, device, seed=rank)
+    cfg = CONFIGS[args.config]
+    W, H, LEVELS, WIN, MAXN = cfg["w"], cfg["h"], cfg["levels"], cfg["win"], cfg["maxn"]
+    B, T = (args.streams or cfg["streams"]), max(2, args.seq)
+    frames = synth_frames(B, T, W, H, device, seed=rank, occlusion=args.occlusion)
     torch.cuda.synchronize()
 
-    p = vsf.default_params(grid_rows=GRID[0], grid_cols=GRID[1], max_features=MAX_FEATURES,
-                           min_distance=MIN_DIST, klt_win=WIN, klt_max_level=LEVELS - 1, klt_max_iter=30,
+    p = vsf.default_params(grid_rows=cfg["rows"], grid_cols=cfg["cols"], max_features=MAXN,
+                           min_distance=cfg["mind"], klt_win=WIN, klt_max_level=LEVELS - 1, klt_max_iter=30,
                            klt_eps=0.01, backtrack_thr=1.0, width=W, height=H, streams=B,
                            device_id=local_rank,
                            detector_kind=vsf.DETECTOR_ANMS if args.detector == "anms" else vsf.DETECTOR_BUCKETING,
@@ -166,7 +247,7 @@ def main():
         ctx.batch_step(frame_ptr(step_i), fstride, W, stream)
         step_i += 1
     ctx.batch_export_tracks(records.data_ptr(), stream)
-    gathered = mg.gather_tracks(records, world, dist)  # the only collective: RCCL all_gather of track records
+    mg.gather_tracks(records, world, dist)  # the only collective: RCCL all_gather of track records
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -188,14 +269,14 @@ def main():
     if rank == 0:
         total_frames = world * B * args.steps
         value = total_frames / dt
-        P, _ = pyramid_bytes(W, H, LEVELS)
+        P = pyramid_bytes(W, H, LEVELS)
         P1 = P - W * H
-        alg_step = 2 * W * H + P1 + 2 * P + 24 * MAX_FEATURES  # 1,806,360 B at C2
-        alg_lk = 2 * P + 24 * MAX_FEATURES                     # the LK kernel's share per frame
+        alg_step = 2 * W * H + P1 + 2 * P + 24 * MAXN  # 1,806,360 B at C2
+        alg_lk = 2 * P + 24 * MAXN                     # the LK kernel's share per frame
         kernel_name = "lk_fb_kernel"
         if args.tracker == "lssd":  # two u8 frames + two sets of u16 levels 1..3 + the table
             p16 = sum(2 * (W >> l) * (H >> l) for l in range(1, 4))
-            alg_lk = 2 * (W * H + p16) + 24 * MAX_FEATURES
+            alg_lk = 2 * (W * H + p16) + 24 * MAXN
             alg_step = 2 * W * H + W * H + p16 + alg_lk
             kernel_name = "lssd_fb_kernel"
         lk_ms, lk_n = prof["lk"]
@@ -203,13 +284,11 @@ def main():
         achieved = alg_lk * B / lk_avg / 1e9 if lk_n else 0.0
         traffic = None
         valu = None
-        tpath = None
-        if args.tracker == "lk":
-            tpath = os.path.join(ROOT, "profiles", "lk_traffic.json")
-        if tpath and os.path.exists(tpath):
+        tpath = os.path.join(ROOT, "profiles", "lk_traffic.json")
+        if args.tracker == "lk" and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("streams") == B:
+                if tj.get("streams") == B and tj.get("config", "C2") == args.config:
                     traffic = tj.get("hbm_bytes_per_launch")
                     if tj.get("valu_insts_per_launch") and lk_n:
                         # the kernel is bound by vector-instruction issue, not bytes: committed SQ_INSTS_VALU count
@@ -221,8 +300,8 @@ def main():
             except Exception:
                 traffic = None
         line = {
-            "metric": "frames/s detect+KLT-track @752x480" if args.tracker == "lk"
-                      else "frames/s detect+LSSD-track @752x480",
+            "metric": "frames/s detect+KLT-track @%dx%d" % (W, H) if args.tracker == "lk"
+                      else "frames/s detect+LSSD-track @%dx%d" % (W, H),
             "value": value,
             "unit": "frames/s",
             "n_gpus": world,
@@ -234,49 +313,61 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/i32 (f32 2x2 solve)",
             "data": "synthetic",
-            "config": {"workload": "C2: synthetic 752x480 8-bit frames, %s, "
-                                   "%s / 300 features, %d streams per GPU resident in HBM"
-                                   % ("4-level pyramid, 21x21 LK window" if args.tracker == "lk"
+            "config": {"workload": "%s, %s, %s / %d features, %d streams per GPU resident in HBM, "
+                                   "%.0f%% of every frame under moving occluders"
+                                   % (cfg["name"],
+                                      "%d-level pyramid, %dx%d LK window" % (LEVELS, WIN, WIN) if args.tracker == "lk"
                                       else "LSSD SE(2) tracker (Pattern24, 3+1 u16 levels, 5 iterations)",
-                                      "4x4 grid" if args.detector == "bucketing" else "ANMS detector", B),
-                       "streams_per_gpu": B, "frames_per_step": world * B,
+                                      "%dx%d grid" % (cfg["cols"], cfg["rows"]) if args.detector == "bucketing"
+                                      else "ANMS detector", MAXN, B, 100 * args.occlusion),
+                       "name": args.config, "streams_per_gpu": B, "frames_per_step": world * B,
                        "mean_features_per_stream": mean_feats, "verified_fraction": kept_frac},
             "roofline": {"bound": "hbm", "kernel": kernel_name, "achieved": achieved, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
                          "avg_launch_ms": lk_avg * 1e3, "algorithmic_bytes_per_launch": alg_lk * B,
-                         "valu_issue": valu},
+                         "valu_issue": valu, "stream_copy_GBps": stream_copy_gbps(device)},
             "step_hbm_frac": alg_step * value / world / HBM_PEAK,
             "kernel_ms": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in prof.items()},
         }
-        if not args.no_cpu and args.detector == "bucketing" and args.tracker == "lk":
-            line["cpu_baseline"] = cpu_baseline(frames, order, args)
-        print(json.dumps(line))
+        if not args.no_cpu and world == 1 and args.detector == "bucketing" and args.tracker == "lk":
+            line["cpu_baseline"] = cpu_baseline(frames, order, cfg)
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()
 
 
-def cpu_baseline(frames, order, args):
-    """Times the CPU oracle (OpenMP over streams) on the first `cpu_streams` streams of the same
-    workload for `cpu_steps` steps; rank 0 at N=1 leg only, bounded to a few seconds."""
+def cpu_baseline(frames, order, cfg):
+    """Times the CPU oracle on the first streams of the same workload: one leg with OpenMP over streams on
+    all host cores, one leg on a single thread; rank 0 at N=1 only, bounded."""
     from oracle import oracle as O
     O.build()
-    S = min(args.cpu_streams, frames.shape[1])
-    host = frames[:, :S].cpu().numpy()  # [T][S][H][W]
-    base = O.StreamsBaseline(S, W, H, MAX_FEATURES + 64, (GRID[0], GRID[1], MAX_FEATURES, MIN_DIST),
-                             (30, 0.01, WIN, LEVELS - 1, 1.0), omp=True)
-    base.step(np.ascontiguousarray(host[order[0]]))  # first frame: detect only (untimed warm-up)
-    t0 = time.perf_counter()
-    for i in range(1, args.cpu_steps + 1):
-        rc = base.step(np.ascontiguousarray(host[order[i % len(order)]]))
-        assert rc == 0
-    dt = time.perf_counter() - t0
-    threads = base.threads
-    base.close()
-    return {"value": S * args.cpu_steps / dt, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "%d streams x %d steps of the same C2 workload, CPU oracle (restated reference CPU "
-                      "path, gcc -O3, OpenMP over streams), %.1f s" % (S, args.cpu_steps, dt)}
+    W, H = cfg["w"], cfg["h"]
+
+    def leg(S, steps, threads):
+        S = min(S, frames.shape[1])
+        host = frames[:, :S].cpu().numpy()  # [T][S][H][W]
+        base = O.StreamsBaseline(S, W, H, cfg["maxn"] + 64, (cfg["rows"], cfg["cols"], cfg["maxn"], cfg["mind"]),
+                                 (30, 0.01, cfg["win"], cfg["levels"] - 1, 1.0), omp=True, threads=threads)
+        base.step(np.ascontiguousarray(host[order[0]]))  # first frame: detect only (untimed warm-up)
+        t0 = time.perf_counter()
+        for i in range(1, steps + 1):
+            rc = base.step(np.ascontiguousarray(host[order[i % len(order)]]))
+            assert rc == 0
+        dt = time.perf_counter() - t0
+        used = base.threads
+        base.close()
+        return S * steps / dt, used, S, steps, dt
+
+    (sa, ka), (s1, k1) = cfg["cpu"]
+    va, ta, sa, ka, da = leg(sa, ka, 0)
+    v1, t1, s1, k1, d1 = leg(s1, k1, 1)
+    return {"value": va, "unit": "frames/s", "cores": ta, "kind": "port",
+            "single_thread": {"value": v1, "cores": t1,
+                              "sample": "%d streams x %d steps, %.1f s" % (s1, k1, d1)},
+            "sample": "%d streams x %d steps of the same workload, CPU oracle (restated reference CPU path, "
+                      "gcc -O3 -march=x86-64-v3 -ffp-contract=off, OpenMP over streams), %.1f s" % (sa, ka, da)}
 
 
 if __name__ == "__main__":

@@ -426,8 +426,9 @@ class StreamsBaseline:
     """Timed CPU baseline: `streams` independent (tracker, detector) pairs stepped together
     (orc_step_streams), OpenMP over streams."""
 
-    def __init__(self, streams, w, h, capacity, det_params, trk_params, omp=True):
+    def __init__(self, streams, w, h, capacity, det_params, trk_params, omp=True, threads=0):
         self.L = lib(omp)
+        self.L.orc_set_threads(int(threads))  # 0 = every core
         self.streams, self.w, self.h, self.capacity = streams, w, h, capacity
         self.trk = (_Tracker * streams)()
         self.det = (_Detector * streams)()

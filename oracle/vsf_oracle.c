@@ -588,6 +588,22 @@ int orc_generate_grid(int w, int h, int cols, int rows, int* rects, float* origi
  * is overwritten in place, exactly like unordered_map::operator[]), others appended.
  * Returns 0, or -1 when capacity is exhausted, -2 when a cell rectangle leaves the image
  * (cv::Mat::operator() would throw). */
+/* The detector's nearest-neighbour rejection (Q5), FeatureDetectorShiTomasiBucketing.cpp:168-185: a corner is kept
+ * when the kd-tree over the PRE-EXISTING features is empty (:172-176; KDTree.cpp:100-102,163-165) or when its
+ * distance to the nearest of them is strictly above min_feature_distance (:178-180).  kd-tree nearest_point ==
+ * exact minimum of the squared distance (kdtree/KDTree.cpp:154-233), so brute force decides the same; pinned
+ * against the reference's own KDTree.cpp by tests/test_ref_kdtree.py (oracle/_ref). */
+int orc_nn_accept(const double* kd_points, int n0, double cx, double cy, double min_feature_distance) {
+  if (n0 <= 0) return 1;
+  double best = 0;
+  for (int i = 0; i < n0; i++) {
+    const double ddx = cx - kd_points[2 * i], ddy = cy - kd_points[2 * i + 1];
+    const double d2 = ddx * ddx + ddy * ddy;
+    if (i == 0 || d2 < best) best = d2;
+  }
+  return sqrt(best) > min_feature_distance; /* :178-180 strict > on the L2 norm */
+}
+
 int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int stride,
                         const uint8_t* mask, int mask_stride, uint64_t* ids, double* xy,
                         uint32_t* age, int* n_inout, int capacity) {
@@ -635,16 +651,7 @@ int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int s
       /* :169 kp.pt.x + grect.x: float + float with the UNROUNDED Rect2f origin */
       const double cx = (double)(pts[2 * k] + origin[2 * c]);
       const double cy = (double)(pts[2 * k + 1] + origin[2 * c + 1]);
-      int accept = 1;
-      if (n0 > 0) {
-        double best = 0;
-        for (int i = 0; i < n0; i++) {
-          const double ddx = cx - kd_points[2 * i], ddy = cy - kd_points[2 * i + 1];
-          const double d2 = ddx * ddx + ddy * ddy;
-          if (i == 0 || d2 < best) best = d2;
-        }
-        accept = sqrt(best) > d->min_feature_distance; /* :178-180 strict > on the L2 norm */
-      }
+      const int accept = orc_nn_accept(kd_points, n0, cx, cy, d->min_feature_distance);
       if (accept) {
         int slot = -1;
         for (int i = 0; i < n; i++)
@@ -1657,6 +1664,17 @@ int orc_num_threads(void) {
   return omp_get_max_threads();
 #else
   return 1;
+#endif
+}
+
+/* threads <= 0: the OpenMP default (all cores) */
+void orc_set_threads(int threads) {
+#ifdef _OPENMP
+  static int dflt = 0;
+  if (!dflt) dflt = omp_get_max_threads();
+  omp_set_num_threads(threads > 0 ? threads : dflt);
+#else
+  (void)threads;
 #endif
 }
 

@@ -230,6 +230,9 @@ int orc_frontend_post_track(const orc_camera_ds* cam, const double* xy, uint32_t
 int orc_step_streams(orc_tracker* trackers, orc_detector* detectors, int streams,
                      const uint8_t* frames, long frame_stride_bytes, int w, int h, int stride,
                      uint64_t* ids, double* xy, uint32_t* age, int* n, int capacity);
+/* Q5 nearest-neighbour rejection against the pre-existing features (FeatureDetectorShiTomasiBucketing.cpp:168-185) */
+int orc_nn_accept(const double* kd_points, int n0, double cx, double cy, double min_feature_distance);
+void orc_set_threads(int threads); /* <= 0: the OpenMP default */
 int orc_num_threads(void);
 
 #ifdef __cplusplus

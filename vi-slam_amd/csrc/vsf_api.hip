@@ -109,9 +109,6 @@ struct vsf_ctx {
   // LK
   LkParams lk;
   LkSmem lks;
-  LkQuadSmem lkq;
-  int lk_ns = 0;          // slots per lane of the two-features-per-wave kernel (1..4)
-  bool lk_quad = false;   // VSF_LK_IMPL=quad selects the experimental four-features-per-wave kernel
   // profiling
   bool prof = false;
   std::vector<EvPair> ev_used;
@@ -221,22 +218,6 @@ int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStr
 
 int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hipStream_t s) {
   ProfScope prof(c, VSF_K_LK, s);
-  if (c->lk_quad) {
-    const int quads = (c->cap + 1) / 2;  // feature pairs per stream
-    dim3 grid((unsigned)(8 * quads * ((streams + 7) / 8)));
-#define VSF_LAUNCH_Q(NS)                                                                                              \
-  hipLaunchKernelGGL((lkq_fb_kernel<NS, 32>), grid, dim3(64), c->lkq.total, s, P, C, c->d_xy, c->d_n, c->cap, quads, \
-                     streams, c->lk, c->d_fwd, c->d_flags)
-    switch (c->lk_ns) {
-      case 1: VSF_LAUNCH_Q(1); break;
-      case 2: VSF_LAUNCH_Q(2); break;
-      case 3: VSF_LAUNCH_Q(3); break;
-      default: VSF_LAUNCH_Q(4); break;
-    }
-#undef VSF_LAUNCH_Q
-    HIPCHK(c, hipGetLastError());
-    return VSF_OK;
-  }
   // workgroups per stream: the table size a detector maintains (+ slack), not the (larger) capacity
   int fgrid = c->p.max_features + 64;
   if (fgrid > c->cap) fgrid = c->cap;
@@ -718,13 +699,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     k.min_eig_c1 = nextafterf((float)((p->min_eig_thr > 0. ? p->min_eig_thr : 0.) * 2.0 * k.win * k.win * 1.001), INFINITY);
     k.backtrack_thr = p->backtrack_thr;
     k.jmargin = 3;
-    k.q_nseg = (k.win + 7) / 8;
-    k.q_seglen = (k.win + k.q_nseg - 1) / k.q_nseg;
-    c->lk_ns = (k.win * k.q_nseg + 31) / 32;  // slots per lane with two features per wave (1..4)
     c->lks = lk_smem_layout(k.win, k.jmargin);
-    c->lkq = lkq_smem_layout(k.win, k.jmargin, 2);
-    const char* impl = getenv("VSF_LK_IMPL");
-    c->lk_quad = impl && strcmp(impl, "quad") == 0;
   }
   // detector grid
   std::vector<int4> rects;
@@ -760,10 +735,6 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     if (want < 2048) want = 2048;
     if (want > 16384) want = 16384;
     if (want > lds_room) want = lds_room & ~255LL;
-    if (const char* e = getenv("VSF_DEBUG_CAND_CAP")) {  // test hook: force the overflow path of select_kernel
-      const long long v = atoll(e);
-      if (v >= 16 && v < want) want = v;
-    }
     c->cand_cap = (int)want;
   }
   c->hash_size = 64;
@@ -1168,28 +1139,16 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
   if (rc) return rc;
   float2 *d_in = nullptr, *d_out = nullptr;
   uint8_t* d_st = nullptr;
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_in), (size_t)n * 8));
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_out), (size_t)n * 8));
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(&d_st), (size_t)n));
-  HIPCHK(c, hipMemcpy(d_in, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice));
+  rc = dalloc(c, &d_in, (size_t)n);
+  if (!rc) rc = dalloc(c, &d_out, (size_t)n);
+  if (!rc) rc = dalloc(c, &d_st, (size_t)n);
+  if (!rc && hipMemcpy(d_in, prev_pts, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) rc = VSF_E_HIP;
   const FrameRef fp = own_ref(c, c->pair_frame[0]), fc = own_ref(c, c->pair_frame[1]);
-  rc = build_pyramid(c, fp, c->pair_pyr[0], 1, nullptr);
+  if (!rc) rc = build_pyramid(c, fp, c->pair_pyr[0], 1, nullptr);
   if (!rc) rc = build_pyramid(c, fc, c->pair_pyr[1], 1, nullptr);
   if (!rc) {
     const PyrView P = make_view(c, fp, c->pair_pyr[0]), C = make_view(c, fc, c->pair_pyr[1]);
-    if (c->lk_quad) {
-      dim3 grid((unsigned)((n + 1) / 2));
-#define VSF_LAUNCH_QP(NS)                                                                                        \
-  hipLaunchKernelGGL((lkq_points_kernel<NS, 32>), grid, dim3(64), c->lkq.total, nullptr, P, C, d_in, n, c->lk, \
-                     d_out, d_st)
-      switch (c->lk_ns) {
-        case 1: VSF_LAUNCH_QP(1); break;
-        case 2: VSF_LAUNCH_QP(2); break;
-        case 3: VSF_LAUNCH_QP(3); break;
-        default: VSF_LAUNCH_QP(4); break;
-      }
-#undef VSF_LAUNCH_QP
-    } else {
+    {
 #define VSF_LAUNCH_WP(SEG)                                                                                      \
   hipLaunchKernelGGL(lk_points_kernel<SEG>, dim3(n), dim3(64), c->lks.total, nullptr, P, C, d_in, n, c->lk, d_out, \
                      d_st)
@@ -1205,9 +1164,9 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
   if (!rc && hipStreamSynchronize(nullptr) != hipSuccess) rc = VSF_E_HIP;
   if (!rc && hipMemcpy(next_pts, d_out, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
   if (!rc && hipMemcpy(status, d_st, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = VSF_E_HIP;
-  (void)hipFree(d_in);
-  (void)hipFree(d_out);
-  (void)hipFree(d_st);
+  if (d_in) (void)hipFree(d_in);
+  if (d_out) (void)hipFree(d_out);
+  if (d_st) (void)hipFree(d_st);
   if (rc == VSF_E_HIP) return fail(c, rc, "vsf_debug_lk: HIP failure");
   return rc;
 }

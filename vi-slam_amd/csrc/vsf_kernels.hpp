@@ -49,8 +49,6 @@ struct LkParams {
   float min_eig_c1;  // max(threshold, 0) * 2 win^2 * 1.001: see the shortcut in lk_track_point
   double backtrack_thr;
   int jmargin;    // extra margin staged around the J window
-  int q_nseg;     // four-features-per-wave variant: segments per window row (<= 8 pixels each)
-  int q_seglen;
 };
 
 // cv: borderInterpolate(p, len, BORDER_REFLECT_101), one reflection, then clamped for memory safety
@@ -1110,10 +1108,6 @@ __global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_points_k
     status[f] = st ? 1 : 0;
   }
 }
-
-}  // namespace vsf
-#include "vsf_lk_quad.hpp"
-namespace vsf {
 
 // Stable in-place compaction of one stream's table by the verified flag; also the three counts
 // the reference logs (FeatureTrackerLucasKanade.cpp:87-104).  One block of 256 threads per stream.
