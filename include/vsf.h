@@ -176,6 +176,10 @@ int vsf_debug_lk(vsf_ctx* ctx, const uint8_t* prev, const uint8_t* next, int32_t
 int vsf_debug_min_eig(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
                       int32_t cell, float* out, int32_t* rect);
 
+/* Test hook: lowers the candidate-key slots select_kernel keeps per grid cell (never above what vsf_create
+ * allocated; >= 16), so that a test can force the exact but slow overflow path of the selection. */
+int vsf_debug_set_cand_cap(vsf_ctx* ctx, int32_t slots);
+
 /* ---- frontend step around the path (KimeraFrontend::ProcessFrame, src/vslam/frontend/KimeraFrontend.cpp:247-304) ---- */
 typedef struct vsf_camera_ds {
   double fx, fy, cx, cy, xi, alpha; /* DoubleSphereCameraModel ctor (src/vslam/data/Camera.cpp:101-122) */

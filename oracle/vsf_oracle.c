@@ -1705,6 +1705,9 @@ int orc_step_streams(orc_tracker* trackers, orc_detector* detectors, int streams
 }
 
 /* test hook: the 3x3 LDLT inverse used by the LSSD patch */
+/* test hook: the sin / cos of SE2::exp in either mode */
+void orc_lssd_debug_sincos(float theta, int mode, float* s, float* c) { lssd_sincos(theta, mode, s, c); }
+
 void orc_lssd_debug_inverse3(const float* H9, float* Hinv9) {
   float H[3][3], Hi[3][3];
   for (int i = 0; i < 3; i++)

@@ -262,3 +262,36 @@ def test_png_chunking_and_size_checks(euroc, tmp_path):
     wide = np.full((23, 40), 9, np.uint8)
     assert L.vsf_png_read_gray8(p.encode(), wide.ctypes.data, 40, 31, 23) == 0
     assert np.array_equal(wide[:, :31], img) and (wide[:, 31:] == 9).all()
+
+
+def test_png_hostile_header_sizes(euroc, synth, tmp_path):
+    """A crafted IHDR must come back as an error code: nothing is allocated from the declared size before it is
+    bounded, zlib's 32-bit output counter cannot be overrun, and no C++ exception crosses the C ABI."""
+    import struct, zlib
+    E = euroc.VsfIoError
+    L = euroc.io_lib()
+
+    def png(w, h, depth=8, ctype=0, payload=b"\0" * 16):
+        return b"\x89PNG\r\n\x1a\n" + _png._chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 0)) + \
+            _png._chunk(b"IDAT", zlib.compress(payload)) + _png._chunk(b"IEND", b"")
+
+    out = np.zeros(64, np.uint8)
+    for w, h in ((0x7fffffff, 0x7fffffff), (0x7fffffff, 1), (1, 0x7fffffff), (70000, 70000), (16385, 16384)):
+        blob = png(w, h)
+        assert L.vsf_png_decode_gray8(blob, len(blob), out.ctypes.data, 0x7fffffff) == euroc.IO_E_FORMAT
+        with pytest.raises(E):
+            euroc.png_info(blob)
+    # inside the pixel bound but far more than the compressed stream can hold (deflate expands <= 1032:1)
+    blob = png(16384, 16384, 16, 4)
+    assert L.vsf_png_decode_gray8(blob, len(blob), out.ctypes.data, 0x7fffffff) == euroc.IO_E_FORMAT
+    assert b"too short" in L.vsf_io_last_error()
+    # the mask path of the provider sizes a buffer from the header too
+    frames, _ = synth.sequence(5, 32, 24, 1)
+    root = str(tmp_path / "d")
+    calib = make_dataset(root, frames, crlf=False)
+    mask = str(tmp_path / "mask.png")
+    for w, h in ((0x7fffffff, 0x7fffffff), (16384, 16384)):
+        open(mask, "wb").write(png(w, h))
+        with pytest.raises(E) as e:
+            euroc.EurocKimeraDataProvider(root, calib, mask)
+        assert e.value.code == euroc.IO_E_FORMAT

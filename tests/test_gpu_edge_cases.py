@@ -164,16 +164,15 @@ def test_strided_host_frames_equal_packed_ones(vsf, synth):
     assert packed == strided and len(packed[-1]) > 10
 
 
-def test_candidate_overflow_path_is_exact(vsf, oracle, synth, monkeypatch):
+def test_candidate_overflow_path_is_exact(vsf, oracle, synth):
     """More thresholded local maxima in a cell than candidate slots: select_kernel re-derives the candidates from
     the lambda map.  The slot count scales with the cell size, so the test forces a small one."""
     w, h = 320, 240
     frames, _ = synth.sequence(23, w, h, 2)
     rng = np.random.default_rng(1)
     noisy = np.clip(frames.astype(np.int32) + rng.integers(-25, 26, frames.shape), 0, 255).astype(np.uint8)
-    monkeypatch.setenv("VSF_DEBUG_CAND_CAP", "64")
     det = vsf.FeatureDetectorShiTomasiBucketing(1, 2, 160, 3.0, w, h, capacity=512)
-    monkeypatch.delenv("VSF_DEBUG_CAND_CAP")
+    det.ctx.debug_set_cand_cap(64)
     db = vsf.FeatureDatabase(512)
     odet, T = oracle.Detector(1, 2, 160, 3.0), oracle.FeatureTable(512)
     for k in range(2):

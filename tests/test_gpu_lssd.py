@@ -279,3 +279,49 @@ def test_tiny_frames_and_deep_pyramids(vsf, oracle, synth):
         for l in range(1, levels + 1):
             assert np.array_equal(got[l - 1], ref[l])
         ctx.close()
+
+
+@pytest.mark.parametrize("seed", [41, 77, 5])
+def test_against_pattern_order_restatement_752x480(vsf, oracle, synth, seed):
+    """The HIP path against the oracle mode that restates the REFERENCE's evaluation (LSSD_SEQ: sums in pattern
+    order, libm sinf / cosf as Sophus::SE2::exp calls them) on detector-produced features at 752x480 over a
+    7-frame sequence, every step started from the same table: identical kept / lost sets after the
+    forward-backward test, and a MAXIMUM deviation of the kept positions of 0.01 px (measured: < 5e-4 px)."""
+    w, h = 752, 480
+    frames, _ = synth.sequence(seed, w, h, 7)
+    P = vsf.FeatureTrackerLSSDLucasKanade.Parameter()
+    trk = vsf.FeatureTrackerLSSDLucasKanade(P, w, h, capacity=512)
+    det = vsf.FeatureDetectorShiTomasiBucketing(4, 4, 300, 10.0, w, h, capacity=512)
+    db = vsf.FeatureDatabase(512)
+    oseq = oracle.LssdTracker(P.optical_flow_max_recovered_dist_, P.optical_flow_levels_,
+                              P.optical_flow_max_iterations_, oracle.LSSD_SEQ)
+    worst, total = 0.0, 0
+    for t, fr in enumerate(frames):
+        S = oracle.FeatureTable(512)
+        S.set(db.ids[:db.n], db.xy[:db.n], db.age[:db.n])
+        trk.Track(db, fr)
+        assert oseq.track(S, fr) == 0
+        a, b = db.as_dict(), S.as_dict()
+        assert a.keys() == b.keys(), "kept sets differ at step %d: %s" % (t, sorted(a.keys() ^ b.keys())[:8])
+        if a:
+            worst = max(worst, max(max(abs(a[i][0] - b[i][0]), abs(a[i][1] - b[i][1])) for i in a))
+            total += len(a)
+        det.UpdateDetection(db, fr)
+    assert total > 500
+    assert worst <= 0.01, "worst deviation %.6f px over %d tracks" % (worst, total)
+
+
+def test_points_validity_and_max_error_against_pattern_order(vsf, oracle, synth):
+    """Forward TrackPoint on detector corners at 752x480: validity identical for >= 99 % of the points and the
+    maximum error on the commonly valid ones <= 0.01 px, against LSSD_SEQ."""
+    w, h = 752, 480
+    ctx = vsf.Context(_params(vsf, w, h))
+    for seed in (1652, 9, 23):
+        frames, _ = synth.sequence(seed, w, h, 2)
+        pts = oracle.good_features_to_track(frames[0], 600, 0.005, 5.0).astype(np.float32)
+        got, ok = ctx.debug_lssd(frames[0], frames[1], pts)
+        seq, sok = oracle.lssd_track_points(frames[0], frames[1], pts, 3, 5, oracle.LSSD_SEQ)
+        assert (ok == sok).mean() >= 0.99
+        both = ok.astype(bool) & sok.astype(bool)
+        assert both.sum() > 200 and np.abs(got - seq)[both].max() <= 0.01
+    ctx.close()

@@ -132,22 +132,3 @@ def test_detector_mask_and_quirks(vsf, oracle, synth):
     odet.update_detection(otab, frames[0])
     assert db.as_dict() == otab.as_dict() and db.n > 0
     assert det.max_feature_index_ == odet.max_feature_index
-
-
-def test_lk_quad_variant_bit_exact(vsf, oracle, synth, monkeypatch):
-    """The experimental several-features-per-wave LK kernel (VSF_LK_IMPL=quad, vsf_lk_quad.hpp; two
-    features of 32 lanes per wave as built) computes
-    exactly what the default kernel computes."""
-    monkeypatch.setenv("VSF_LK_IMPL", "quad")
-    for (w, h, win, ml) in [(752, 480, 21, 3), (400, 300, 15, 3), (400, 300, 31, 2), (320, 240, 24, 3)]:
-        frames = _seq(synth, 13, w, h, 2)
-        rng = np.random.default_rng(9)
-        n = 403
-        pts = np.stack([rng.uniform(-5, w + 5, n), rng.uniform(-5, h + 5, n)], 1).astype(np.float32)
-        ctx = vsf.Context(vsf.default_params(width=w, height=h, klt_win=win, klt_max_level=ml))
-        got, gst = ctx.debug_lk(frames[0], frames[1], pts)
-        ref, rst, _ = oracle.calc_optical_flow_pyr_lk(frames[0], frames[1], pts, win, ml, 30, 0.01,
-                                                      acc_mode=oracle.ACC_EXACT)
-        assert np.array_equal(gst, rst)
-        assert np.array_equal(got[gst == 1].view(np.uint32), ref[rst == 1].view(np.uint32))
-        ctx.close()

@@ -143,3 +143,30 @@ def test_tracker_keeps_its_own_translation_per_id(oracle, synth):
     assert seen["a"] not in got
     if seen["b"] in got:
         assert got[999][:2] == got[seen["b"]][:2]
+
+
+def test_se2_exp_polynomial_against_libm(oracle):
+    """SE2::exp's sin / cos: the reference calls libm (LSSD_SEQ); the wavefront-exact mode the HIP kernel is held
+    to (LSSD_TREE) evaluates Taylor polynomials (degree 9 / 10).  Over |theta| <= 1 rad -- an increment of 57
+    degrees in ONE Gauss-Newton step; the rotation increments the tracker produces on the test sequences stay
+    below 0.2 rad -- the polynomial is within 1.5 float ulp of the correctly rounded value and within 1e-7 of
+    libm's sinf / cosf; beyond |theta| = 2 it degrades (5e-5 at 2 rad), where a patch has long failed its
+    validity test."""
+    import ctypes as C
+    fn = oracle.lib().orc_lssd_debug_sincos
+    fn.argtypes = [C.c_float, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    th = np.concatenate([np.linspace(-1, 1, 20001), np.float32(10.0) ** np.linspace(-8, 0, 400),
+                         -(np.float32(10.0) ** np.linspace(-8, 0, 400))]).astype(np.float32)
+    worst_ulp = worst_abs = 0.0
+    for t in th:
+        s, c, s2, c2 = C.c_float(), C.c_float(), C.c_float(), C.c_float()
+        fn(float(t), oracle.LSSD_TREE, C.byref(s), C.byref(c))
+        fn(float(t), oracle.LSSD_SEQ, C.byref(s2), C.byref(c2))
+        for got, lib, true in ((s.value, s2.value, np.sin(np.float64(t))), (c.value, c2.value, np.cos(np.float64(t)))):
+            ulp = np.spacing(np.float32(abs(true))) if true != 0 else np.float32(1e-45)
+            worst_ulp = max(worst_ulp, abs(got - true) / float(ulp))
+            worst_abs = max(worst_abs, abs(got - lib))
+    assert worst_ulp <= 1.5 and worst_abs <= 1.2e-7, (worst_ulp, worst_abs)
+    s, c = C.c_float(), C.c_float()
+    fn(2.0, oracle.LSSD_TREE, C.byref(s), C.byref(c))
+    assert abs(s.value - np.sin(2.0)) < 1e-4

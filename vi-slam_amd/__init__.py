@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "vsf_batch_upload", "vsf_batch_download", "vsf_batch_device_tables", "vsf_batch_status",
     "vsf_batch_export_tracks",
     "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig", "vsf_debug_anms",
+    "vsf_debug_set_cand_cap",
     "vsf_batch_frontend_post_track", "vsf_unproject", "vsf_debug_lssd", "vsf_debug_lssd_pyramid", "vsf_debug_lssd_inverse3",
     "vsf_profile_enable", "vsf_profile_read",
 ]
@@ -290,6 +291,9 @@ class Context:
         self._chk(lib().vsf_debug_min_eig(self._h, _vp(img), w, h, w, cell, _vp(out), rect))
         rx, ry, rw, rh = [int(v) for v in rect]
         return out[:rw * rh].reshape(rh, rw).copy(), (rx, ry, rw, rh)
+
+    def debug_set_cand_cap(self, slots):
+        self._chk(lib().vsf_debug_set_cand_cap(self._h, int(slots)))
 
     def debug_lssd(self, prev, nxt, pts):
         prev = np.ascontiguousarray(prev, np.uint8)

@@ -67,7 +67,7 @@ struct vsf_ctx {
   int* d_status = nullptr;
   uint64_t* d_maxidx = nullptr;
   // detector
-  int ncell = 0, grid_max = 0, lam_total = 0, cand_cap = 0, hash_size = 0;
+  int ncell = 0, grid_max = 0, lam_total = 0, cand_cap = 0, cand_cap_alloc = 0, hash_size = 0;
   int max_cw = 0, max_ch = 0;
   int4* d_rects = nullptr;
   float2* d_origin = nullptr;
@@ -736,6 +736,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     if (want > 16384) want = 16384;
     if (want > lds_room) want = lds_room & ~255LL;
     c->cand_cap = (int)want;
+    c->cand_cap_alloc = c->cand_cap;
   }
   c->hash_size = 64;
   while (c->hash_size < 2 * c->cap) c->hash_size <<= 1;
@@ -1171,6 +1172,12 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
   return rc;
 }
 
+int vsf_debug_set_cand_cap(vsf_ctx* c, int32_t slots) {
+  if (!c || slots < 16) return VSF_E_INVALID;
+  c->cand_cap = slots < c->cand_cap_alloc ? slots : c->cand_cap_alloc;
+  return VSF_OK;
+}
+
 int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t cell,
                       float* out, int32_t* rect) {
   if (!c || !img || !out || cell < 0 || cell >= c->ncell) return VSF_E_INVALID;
@@ -1363,6 +1370,19 @@ int vsf_debug_anms(vsf_ctx* c, int32_t stream, uint8_t* flag_out, int16_t* kp_ou
   if (n_kp_out) *n_kp_out = nd;
   return VSF_OK;
 }
+
+#ifdef VSF_LK_STATS
+// instrumented build only (not declared in include/vsf.h): reads and optionally clears the LK counters
+int vsf_debug_lk_stats(unsigned long long* out /* [512] */, int32_t reset) {
+  if (hipDeviceSynchronize() != hipSuccess) return VSF_E_HIP;
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lk_stats), sizeof(g_lk_stats)) != hipSuccess) return VSF_E_HIP;
+  if (reset) {
+    static unsigned long long zeros[512];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_lk_stats), zeros, sizeof(zeros)) != hipSuccess) return VSF_E_HIP;
+  }
+  return VSF_OK;
+}
+#endif
 
 int vsf_profile_enable(vsf_ctx* c, int32_t on) {
   if (!c) return VSF_E_INVALID;

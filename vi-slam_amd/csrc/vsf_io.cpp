@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <string>
+#include <new>
 #include <vector>
 
 namespace {
@@ -48,6 +49,8 @@ bool read_file(const std::string& path, std::vector<uint8_t>& out) {
 // ---------------------------------------------------------------------------------------------------
 // PNG
 // ---------------------------------------------------------------------------------------------------
+constexpr uint64_t VSF_PNG_MAX_PIXELS = 1ull << 28;
+
 struct PngHeader {
   uint32_t w = 0, h = 0;
   int depth = 0, ctype = 0, interlace = 0;
@@ -77,6 +80,8 @@ int png_parse(const uint8_t* d, size_t n, PngHeader& hd, std::vector<uint8_t>* i
       hd.interlace = data[12];
       if (data[10] != 0 || data[11] != 0 || hd.interlace > 1) return fail(VSF_IO_E_FORMAT, "png: bad IHDR methods");
       if (hd.w == 0 || hd.h == 0 || hd.w > 0x7fffffffu || hd.h > 0x7fffffffu) return fail(VSF_IO_E_FORMAT, "png: bad size");
+      // nothing is allocated from a file-declared size beyond this bound (2^28 pixels, e.g. 16384 x 16384)
+      if ((uint64_t)hd.w * hd.h > VSF_PNG_MAX_PIXELS) return fail(VSF_IO_E_FORMAT, "png: declared size exceeds 2^28 pixels");
       have_ihdr = true;
       if (!idat) return VSF_IO_OK;  // header only
     } else if (std::memcmp(type, "IDAT", 4) == 0) {
@@ -130,7 +135,12 @@ int png_decode(const uint8_t* d, size_t n, uint8_t* out, int32_t out_stride, int
   const size_t bits_pp = (size_t)channels * hd.depth;
   const size_t rowbytes = ((size_t)hd.w * bits_pp + 7) / 8;
   const size_t bpp = bits_pp >= 8 ? bits_pp / 8 : 1;
-  std::vector<uint8_t> raw((rowbytes + 1) * (size_t)hd.h);
+  // deflate expands by at most 1032:1, so a stream this short cannot hold the declared image; and zlib's
+  // avail_out is 32 bits wide
+  const uint64_t raw_size = ((uint64_t)rowbytes + 1) * hd.h;
+  if (raw_size > (uint64_t)idat.size() * 1032 + 64 || raw_size > 0xffffffffull)
+    return fail(VSF_IO_E_FORMAT, "png: compressed data is too short for the declared size");
+  std::vector<uint8_t> raw((size_t)raw_size);
   z_stream zs;
   std::memset(&zs, 0, sizeof(zs));
   if (inflateInit(&zs) != Z_OK) return fail(VSF_IO_E_FORMAT, "png: inflateInit failed");
@@ -577,12 +587,27 @@ struct vsf_euroc {
   std::vector<uint8_t> file_buf;
 };
 
+// Nothing throws across the C ABI: std::bad_alloc / length_error from a container become an error code.
+template <class F>
+int guarded(F&& f) {
+  try {
+    return f();
+  } catch (const std::bad_alloc&) {
+    return fail(VSF_IO_E_FORMAT, "out of memory");
+  } catch (const std::exception& e) {
+    return fail(VSF_IO_E_FORMAT, std::string("exception: ") + e.what());
+  } catch (...) {
+    return fail(VSF_IO_E_FORMAT, "unknown exception");
+  }
+}
+
 extern "C" {
 
 const char* vsf_io_last_error(void) { return g_err.c_str(); }
 
 int vsf_png_info(const uint8_t* file, size_t nbytes, int32_t* width, int32_t* height, int32_t* bit_depth,
                  int32_t* color_type) {
+  return guarded([&]() -> int {
   PngHeader hd;
   const int rc = png_parse(file, nbytes, hd, nullptr);
   if (rc) return rc;
@@ -591,22 +616,28 @@ int vsf_png_info(const uint8_t* file, size_t nbytes, int32_t* width, int32_t* he
   if (bit_depth) *bit_depth = hd.depth;
   if (color_type) *color_type = hd.ctype;
   return VSF_IO_OK;
+  });
 }
 
 int vsf_png_decode_gray8(const uint8_t* file, size_t nbytes, uint8_t* out, int32_t out_stride) {
+  return guarded([&]() -> int {
   return png_decode(file, nbytes, out, out_stride, 0, 0);
+  });
 }
 
 int vsf_png_read_gray8(const char* path, uint8_t* out, int32_t out_stride, int32_t expect_width,
                        int32_t expect_height) {
+  return guarded([&]() -> int {
   if (!path) return fail(VSF_IO_E_INVALID, "null path");
   std::vector<uint8_t> buf;
   if (!read_file(path, buf)) return fail(VSF_IO_E_FILE, std::string("cannot open ") + path);
   return png_decode(buf.data(), buf.size(), out, out_stride, expect_width, expect_height);
+  });
 }
 
 int vsf_euroc_open(const char* path_to_dataset_root, const char* path_to_calibration_file,
                    const char* path_to_mask_image, vsf_euroc** out) {
+  return guarded([&]() -> int {
   if (!path_to_dataset_root || !path_to_calibration_file || !out) return fail(VSF_IO_E_INVALID, "null argument");
   *out = nullptr;
   std::unique_ptr<vsf_euroc> e(new vsf_euroc);
@@ -639,25 +670,31 @@ int vsf_euroc_open(const char* path_to_dataset_root, const char* path_to_calibra
   }
   *out = e.release();
   return VSF_IO_OK;
+  });
 }
 
 void vsf_euroc_close(vsf_euroc* e) { delete e; }
 
 int vsf_euroc_size(const vsf_euroc* e, uint64_t* n_frames) {
+  return guarded([&]() -> int {
   if (!e || !n_frames) return fail(VSF_IO_E_INVALID, "null argument");
   *n_frames = e->logs.size();
   return VSF_IO_OK;
+  });
 }
 
 int vsf_euroc_entry(const vsf_euroc* e, uint64_t index, uint64_t* timestamp_ns, const char** filename) {
+  return guarded([&]() -> int {
   if (!e) return fail(VSF_IO_E_INVALID, "null argument");
   if (index >= e->logs.size()) return fail(VSF_IO_E_RANGE, "Reached the last line.");
   if (timestamp_ns) *timestamp_ns = e->logs[index].timestamp_ns;
   if (filename) *filename = e->logs[index].filename.c_str();
   return VSF_IO_OK;
+  });
 }
 
 int vsf_euroc_frame_size(vsf_euroc* e, int32_t* width, int32_t* height) {
+  return guarded([&]() -> int {
   if (!e || !width || !height) return fail(VSF_IO_E_INVALID, "null argument");
   if (e->fw == 0) {
     if (e->logs.empty()) return fail(VSF_IO_E_RANGE, "data.csv holds no frames");
@@ -672,10 +709,12 @@ int vsf_euroc_frame_size(vsf_euroc* e, int32_t* width, int32_t* height) {
   *width = e->fw;
   *height = e->fh;
   return VSF_IO_OK;
+  });
 }
 
 int vsf_euroc_frame(vsf_euroc* e, uint64_t index, double* timestamp_s, uint8_t* out, int32_t out_stride,
                     int32_t width, int32_t height) {
+  return guarded([&]() -> int {
   if (!e || !out) return fail(VSF_IO_E_INVALID, "null argument");
   if (index >= e->logs.size()) return fail(VSF_IO_E_RANGE, "Reached the last line.");  // :71-74 -> std::nullopt
   const std::string path = e->root + "/mav0/cam0/data/" + e->logs[index].filename;     // :76-77
@@ -684,16 +723,20 @@ int vsf_euroc_frame(vsf_euroc* e, uint64_t index, double* timestamp_s, uint8_t* 
   if (rc) return rc;
   if (timestamp_s) *timestamp_s = static_cast<double>(e->logs[index].timestamp_ns) * 1e-9;  // :82
   return VSF_IO_OK;
+  });
 }
 
 int vsf_euroc_camera_model(const vsf_euroc* e, vsf_euroc_camera* out) {
+  return guarded([&]() -> int {
   if (!e || !out) return fail(VSF_IO_E_INVALID, "null argument");
   *out = e->cam;
   return VSF_IO_OK;
+  });
 }
 
 int vsf_euroc_mask(const vsf_euroc* e, int32_t* has_mask, int32_t* width, int32_t* height, uint8_t* out,
                    int32_t out_stride) {
+  return guarded([&]() -> int {
   if (!e || !has_mask) return fail(VSF_IO_E_INVALID, "null argument");
   *has_mask = e->mask.empty() ? 0 : 1;
   if (width) *width = e->mask_w;
@@ -703,13 +746,16 @@ int vsf_euroc_mask(const vsf_euroc* e, int32_t* has_mask, int32_t* width, int32_
     for (int32_t y = 0; y < e->mask_h; y++) std::memcpy(out + (size_t)y * out_stride, e->mask.data() + (size_t)y * e->mask_w, (size_t)e->mask_w);
   }
   return VSF_IO_OK;
+  });
 }
 
 int vsf_euroc_sensor_pose(const vsf_euroc* e, double* rotation9, double* translation3) {
+  return guarded([&]() -> int {
   if (!e || !rotation9 || !translation3) return fail(VSF_IO_E_INVALID, "null argument");
   std::memcpy(rotation9, e->R, sizeof(e->R));
   std::memcpy(translation3, e->t, sizeof(e->t));
   return VSF_IO_OK;
+  });
 }
 
 }  // extern "C"

@@ -23,6 +23,23 @@
 #define VSF_SUM_LDS 1  // exact sums through the LDS atomic unit (0: DPP + v_readlane only)
 #endif
 
+// Instrumented build only (-DVSF_LK_STATS, scratch/lk_stats.py): per-level counters of the LK kernel.
+//   [level*16 + 0] levels entered in range   [+1] levels that passed the min-eigenvalue test   [+2] iterations
+//   [+3] J region stagings   [+4] interior (register Scharr) set-ups   [+5] ended by |delta| <= eps
+//   [+6] ended by the oscillation rule   [+7] ended by max_count   [+8] left the image
+//   [128 + level*32 + min(iterations, 31)] histogram of iterations per level
+#ifdef VSF_LK_STATS
+__device__ unsigned long long g_lk_stats[512];
+#define VSF_LKSTAT(i)                                                        \
+  do {                                                                       \
+    if ((threadIdx.x & 63) == 0) atomicAdd(&g_lk_stats[(i)], 1ull);          \
+  } while (0)
+#else
+#define VSF_LKSTAT(i) \
+  do {                \
+  } while (0)
+#endif
+
 namespace vsf {
 
 constexpr int MAXL = 8;      // pyramid levels supported (klt_max_level <= 7)
@@ -741,6 +758,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       }
     }
     __syncthreads();
+    if (in_range) VSF_LKSTAT(level * 16 + 0);
 
     const uint8_t* Bb = B.base[level] + (long long)stream * B.sstride[level];
     const int bp = B.pitch[level], bw = B.w[level], bh = B.h[level];
@@ -764,6 +782,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       // every tap of every window pixel lies inside the level image: no zero-padded gradient involved
       const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < aw && ipy + win < ah;
       if (interior) {
+        VSF_LKSTAT(level * 16 + 4);
         // Fast path.  The Scharr operator and the bilinear interpolation are both linear and integer,
         // so sum_w(w * Scharr(I)) == Scharr(V) with V = sum_w(w * I) (22 bits) evaluated on the window
         // grid plus a one-pixel ring.  Each lane forms V on 3 rows x (SEG+2) columns from 4 patch
@@ -918,6 +937,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     }
 
     if (level_ok) {
+      VSF_LKSTAT(level * 16 + 1);
+      int n_iter = 0, end_kind = 7;
       D = 1.f / D;
       bool staged = false;
       float cx = nx - half, cy = ny - half;  // nextPt - halfWin
@@ -927,8 +948,10 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         const int iny = __builtin_amdgcn_readfirstlane((int)floorf(cy));
         if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
           if (level == 0) status = false;
+          end_kind = 8;
           break;
         }
+        n_iter++;
         if (!staged || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + 4 * L.gj.ndw ||
             iny + win + 1 > jy0 + L.gj.rows) {
           __syncthreads();  // previous iteration's reads are done
@@ -942,6 +965,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
             region_stage_slow_pairs<NJ>(sJ, Bb, bp, bw, bh, jx0, jy0, L.gj, L.jp_pitch, lane);
           }
           staged = true;
+          VSF_LKSTAT(level * 16 + 3);
           __syncthreads();
         }
         int iw00, iw01, iw10, iw11;
@@ -1005,18 +1029,32 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
             conv = false;
           else
             conv = (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2;
-          if (conv) break;
+          if (conv) {
+            end_kind = 5;
+            break;
+          }
         }
         // cv compares the float sums with the double 0.01; (float)0.01 is the largest float below
         // 0.01, so `<= 0.01f` in float is the same predicate
         if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
           nx -= dx * 0.5f;
           ny -= dy * 0.5f;
+          end_kind = 6;
           break;
         }
         pdx = dx;
         pdy = dy;
       }
+#ifdef VSF_LK_STATS
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_lk_stats[level * 16 + 2], (unsigned long long)n_iter);
+        atomicAdd(&g_lk_stats[level * 16 + end_kind], 1ull);
+        atomicAdd(&g_lk_stats[128 + level * 32 + (n_iter < 31 ? n_iter : 31)], 1ull);
+      }
+#else
+      (void)n_iter;
+      (void)end_kind;
+#endif
       // cv: with err requested (the reference always passes an err vector) the final position is
       // range-checked once more at level 0
       if (status && level == 0) {
