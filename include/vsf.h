@@ -223,6 +223,19 @@ int vsf_debug_lssd_pyramid(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t 
  * keypoints in cv order as x, y int16 pairs (kp may be NULL; at most anms_detection_features pairs). */
 int vsf_debug_anms(vsf_ctx* ctx, int32_t stream, uint8_t* flag_out, int16_t* kp_out, int32_t* n_kp_out);
 
+/* ---- one entry point that allocates nothing ----
+ * No counterpart in the reference: it exists for callers that cannot call hipMalloc (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid allocation).  cv::calcOpticalFlowPyrLK on n points like
+ * vsf_debug_lk, but frames, points, next points and status are DEVICE pointers the caller owns, there is no
+ * context, and the scratch the kernels need (levels >= 1 of both pyramids) lives in a 4 MiB device array inside
+ * the library (one copy per GPU, held until the process ends).  p supplies width, height, klt_* , min_eig_thr and
+ * device_id.  Frames whose two pyramids do not fit 4 MiB (above about 5.9 Mpixel) return VSF_E_CAPACITY.  The
+ * call only enqueues kernels on hip_stream; it calls no hipMalloc / hipFree.  All calls on one GPU share that
+ * GPU's array: calls that overlap on one GPU (different streams, threads) race; serialise them. */
+int vsf_lk_points_noalloc(const vsf_params* p, const uint8_t* d_prev, int32_t prev_stride, const uint8_t* d_next,
+                          int32_t next_stride, const float* d_prev_pts, float* d_next_pts, uint8_t* d_status,
+                          int32_t n, void* hip_stream);
+
 /* ---- in-library kernel timing (HIP events on the launch stream), used by bench.py ---- */
 #define VSF_K_PYRAMID 0
 #define VSF_K_LK 1

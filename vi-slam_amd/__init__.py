@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig", "vsf_debug_anms",
     "vsf_debug_set_cand_cap",
     "vsf_batch_frontend_post_track", "vsf_unproject", "vsf_debug_lssd", "vsf_debug_lssd_pyramid", "vsf_debug_lssd_inverse3",
-    "vsf_profile_enable", "vsf_profile_read",
+    "vsf_profile_enable", "vsf_profile_read", "vsf_lk_points_noalloc",
 ]
 
 
@@ -360,6 +360,15 @@ class Context:
         cnt = (C.c_int32 * len(KERNEL_NAMES))()
         self._chk(lib().vsf_profile_read(self._h, ms, cnt))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+
+def lk_points_noalloc(params, d_prev, prev_stride, d_next, next_stride, d_prev_pts, d_next_pts, d_status, n, stream=0):
+    """vsf_lk_points_noalloc: every pointer is a raw DEVICE address; allocates nothing (include/vsf.h)."""
+    rc = lib().vsf_lk_points_noalloc(C.byref(params), C.c_void_p(d_prev), prev_stride, C.c_void_p(d_next), next_stride,
+                                     C.c_void_p(d_prev_pts), C.c_void_p(d_next_pts), C.c_void_p(d_status), n,
+                                     C.c_void_p(stream))
+    if rc != VSF_OK:
+        raise VsfError(rc, "vsf_lk_points_noalloc failed")
 
 
 class FeatureDatabase:

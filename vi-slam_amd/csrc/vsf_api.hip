@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 #include "vsf_kernels.hpp"
@@ -186,6 +187,48 @@ PyrView make_view(const vsf_ctx* c, const FrameRef& f, const PyrSet& ps) {
   return v;
 }
 
+// pyramid geometry: cv::buildOpticalFlowPyramid stops when the NEXT level would be <= the window
+int lk_pyramid_geometry(int width, int height, int win, int max_level, int* lw, int* lh, int* lp) {
+  int w = width, h = height, l = 0;
+  for (;; l++) {
+    lw[l] = w;
+    lh[l] = h;
+    lp[l] = (w + 3) & ~3;
+    w = (w + 1) / 2;
+    h = (h + 1) / 2;
+    if (l == max_level || w <= win || h <= win) break;
+  }
+  return l + 1;
+}
+
+// LK lane mapping and the clamped termination criteria
+LkParams make_lk_params(const vsf_params* p) {
+  LkParams k;
+  memset(&k, 0, sizeof(k));
+  k.win = p->klt_win;
+  k.nseg = 64 / k.win;
+  k.seglen = (k.win + k.nseg - 1) / k.nseg;
+  k.nseg_inv = (65536 + k.nseg - 1) / k.nseg;
+  int mc = p->klt_max_iter;  // cv: TermCriteria clamp
+  mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);
+  k.max_count = mc;
+  double e = p->klt_eps;
+  e = e < 0. ? 0. : (e > 10. ? 10. : e);
+  k.eps2 = e * e;
+  if (k.eps2 >= 1e-30) {
+    k.eps2_lo = nextafterf((float)(k.eps2 * (1.0 - 1e-6)), 0.f);
+    k.eps2_hi = nextafterf((float)(k.eps2 * (1.0 + 1e-6)), INFINITY);
+  } else {  // degenerate eps: always decide in double
+    k.eps2_lo = -1.f;
+    k.eps2_hi = INFINITY;
+  }
+  k.min_eig_thr = p->min_eig_thr;
+  k.min_eig_c1 = nextafterf((float)((p->min_eig_thr > 0. ? p->min_eig_thr : 0.) * 2.0 * k.win * k.win * 1.001), INFINITY);
+  k.backtrack_thr = p->backtrack_thr;
+  k.jmargin = 3;
+  return k;
+}
+
 int alloc_pyr(vsf_ctx* c, PyrSet* ps, int streams) {
   for (int l = 1; l < c->nlevels; l++) {
     int rc = dalloc(c, &ps->lv[l], (size_t)streams * c->lp[l] * c->lh[l] + 16);
@@ -194,24 +237,29 @@ int alloc_pyr(vsf_ctx* c, PyrSet* ps, int streams) {
   return VSF_OK;
 }
 
-// cv::buildOpticalFlowPyramid levels >= 1 (level 0 is the frame itself)
+// cv::buildOpticalFlowPyramid levels >= 1 (level 0 is the frame itself); lv[l] = level l of stream 0
+void launch_pyramid(const FrameRef& f, uint8_t* const* lv, int nlevels, const int* lw, const int* lh, const int* lp,
+                    int streams, hipStream_t s) {
+  for (int l = 1; l < nlevels; l++) {
+    const uint8_t* src = (l == 1) ? f.ptr : lv[l - 1];
+    const long long sst = (l == 1) ? f.sstride : (long long)lp[l - 1] * lh[l - 1];
+    const int sp = (l == 1) ? f.pitch : lp[l - 1];
+    dim3 grid((lw[l] + PD_TW - 1) / PD_TW, (lh[l] + PD_TH - 1) / PD_TH, streams);
+    const long long dst_sst = (long long)lp[l] * lh[l];
+    const bool aligned = ((uintptr_t)src % 4 == 0) && sst % 4 == 0 && sp % 4 == 0 && lw[l - 1] % 4 == 0 &&
+                         lw[l - 1] >= 8 && ((uintptr_t)lv[l] % 4 == 0) && dst_sst % 4 == 0 && lp[l] % 4 == 0;
+    if (aligned)
+      hipLaunchKernelGGL(pyr_down_dword_kernel<false>, grid, dim3(256), 0, s, src, sst, sp, lw[l - 1], lh[l - 1],
+                         (void*)lv[l], dst_sst, lp[l], lw[l], lh[l]);
+    else
+      hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src, sst, sp, lw[l - 1], lh[l - 1], lv[l], dst_sst,
+                         lp[l], lw[l], lh[l]);
+  }
+}
+
 int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStream_t s) {
   ProfScope prof(c, VSF_K_PYRAMID, s);
-  for (int l = 1; l < c->nlevels; l++) {
-    const uint8_t* src = (l == 1) ? f.ptr : ps.lv[l - 1];
-    const long long sst = (l == 1) ? f.sstride : (long long)c->lp[l - 1] * c->lh[l - 1];
-    const int sp = (l == 1) ? f.pitch : c->lp[l - 1];
-    dim3 grid((c->lw[l] + PD_TW - 1) / PD_TW, (c->lh[l] + PD_TH - 1) / PD_TH, streams);
-    const long long dst_sst = (long long)c->lp[l] * c->lh[l];
-    const bool aligned = ((uintptr_t)src % 4 == 0) && sst % 4 == 0 && sp % 4 == 0 && c->lw[l - 1] % 4 == 0 &&
-                         c->lw[l - 1] >= 8 && ((uintptr_t)ps.lv[l] % 4 == 0) && dst_sst % 4 == 0 && c->lp[l] % 4 == 0;
-    if (aligned)
-      hipLaunchKernelGGL(pyr_down_dword_kernel<false>, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
-                         (void*)ps.lv[l], dst_sst, c->lp[l], c->lw[l], c->lh[l]);
-    else
-      hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src, sst, sp, c->lw[l - 1], c->lh[l - 1],
-                         ps.lv[l], dst_sst, c->lp[l], c->lw[l], c->lh[l]);
-  }
+  launch_pyramid(f, ps.lv, c->nlevels, c->lw, c->lh, c->lp, streams, s);
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
 }
@@ -662,45 +710,9 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   c->cap = p->capacity > 0 ? p->capacity : p->max_features + 64 + (use_anms ? anms_k : 0);
   const int B = c->B;
 
-  // pyramid geometry: cv::buildOpticalFlowPyramid stops when the NEXT level would be <= the window
-  {
-    int w = p->width, h = p->height, l = 0;
-    for (;; l++) {
-      c->lw[l] = w;
-      c->lh[l] = h;
-      c->lp[l] = (w + 3) & ~3;
-      w = (w + 1) / 2;
-      h = (h + 1) / 2;
-      if (l == p->klt_max_level || w <= p->klt_win || h <= p->klt_win) break;
-    }
-    c->nlevels = l + 1;
-  }
-  // LK lane mapping
-  {
-    LkParams& k = c->lk;
-    k.win = p->klt_win;
-    k.nseg = 64 / k.win;
-    k.seglen = (k.win + k.nseg - 1) / k.nseg;
-    k.nseg_inv = (65536 + k.nseg - 1) / k.nseg;
-    int mc = p->klt_max_iter;  // cv: TermCriteria clamp
-    mc = mc < 0 ? 0 : (mc > 100 ? 100 : mc);
-    k.max_count = mc;
-    double e = p->klt_eps;
-    e = e < 0. ? 0. : (e > 10. ? 10. : e);
-    k.eps2 = e * e;
-    if (k.eps2 >= 1e-30) {
-      k.eps2_lo = nextafterf((float)(k.eps2 * (1.0 - 1e-6)), 0.f);
-      k.eps2_hi = nextafterf((float)(k.eps2 * (1.0 + 1e-6)), INFINITY);
-    } else {  // degenerate eps: always decide in double
-      k.eps2_lo = -1.f;
-      k.eps2_hi = INFINITY;
-    }
-    k.min_eig_thr = p->min_eig_thr;
-    k.min_eig_c1 = nextafterf((float)((p->min_eig_thr > 0. ? p->min_eig_thr : 0.) * 2.0 * k.win * k.win * 1.001), INFINITY);
-    k.backtrack_thr = p->backtrack_thr;
-    k.jmargin = 3;
-    c->lks = lk_smem_layout(k.win, k.jmargin);
-  }
+  c->nlevels = lk_pyramid_geometry(p->width, p->height, p->klt_win, p->klt_max_level, c->lw, c->lh, c->lp);
+  c->lk = make_lk_params(p);
+  c->lks = lk_smem_layout(c->lk.win, c->lk.jmargin);
   // detector grid
   std::vector<int4> rects;
   std::vector<float2> origin;
@@ -1217,6 +1229,100 @@ int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
     rect[3] = r.w;
   }
   return VSF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One entry point that allocates nothing (callers under HIP graph capture, tight serving loops, harnesses
+// that forbid hipMalloc): cv::calcOpticalFlowPyrLK on device-resident frames and points, like vsf_debug_lk,
+// with the two pyramids (levels >= 1) in a file-scope device array instead of hipMalloc'ed buffers.
+// Every call on a GPU shares that GPU's array: calls that overlap on one GPU race.
+// ------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+#define VSF_NOALLOC_SCRATCH_BYTES (4u << 20)
+static __device__ __align__(256) uint8_t vsf_noalloc_scratch[VSF_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int NOALLOC_MAX_DEV = 64;
+uint8_t* g_noalloc_ptr[NOALLOC_MAX_DEV];  // device address of the array on each GPU (each holds its own copy)
+std::mutex g_noalloc_mu;
+
+// `vsf_noalloc_scratch` in host code is a host-side stand-in, not a device address: the address comes from
+// hipGetSymbolAddress, once per device, with that device current.
+int noalloc_scratch_ptr(int dev, uint8_t** out) {
+  if (dev < 0 || dev >= NOALLOC_MAX_DEV) return VSF_E_INVALID;
+  std::lock_guard<std::mutex> lock(g_noalloc_mu);
+  if (!g_noalloc_ptr[dev]) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(vsf_noalloc_scratch)) != hipSuccess || !p) return VSF_E_HIP;
+    g_noalloc_ptr[dev] = static_cast<uint8_t*>(p);
+  }
+  *out = g_noalloc_ptr[dev];
+  return VSF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vsf_lk_points_noalloc(const vsf_params* p, const uint8_t* d_prev, int32_t prev_stride, const uint8_t* d_next,
+                          int32_t next_stride, const float* d_prev_pts, float* d_next_pts, uint8_t* d_status,
+                          int32_t n, void* hip_stream) {
+  if (!p || !d_prev || !d_next || n < 0) return VSF_E_INVALID;
+  if (n == 0) return VSF_OK;
+  if (!d_prev_pts || !d_next_pts || !d_status) return VSF_E_INVALID;
+  if (p->width <= 0 || p->height <= 0 || prev_stride < p->width || next_stride < p->width) return VSF_E_INVALID;
+  if (p->klt_win < 3 || p->klt_win > MAX_WIN || p->klt_max_level < 0 || p->klt_max_level >= MAXL ||
+      p->width <= p->klt_win || p->height <= p->klt_win)
+    return VSF_E_INVALID;
+  int lw[MAXL], lh[MAXL], lp[MAXL];
+  const int nlevels = lk_pyramid_geometry(p->width, p->height, p->klt_win, p->klt_max_level, lw, lh, lp);
+  // carve the two pyramids out of the array: level l of pyramid k, 256-byte aligned
+  size_t off = 0;
+  size_t lv_off[2][MAXL] = {};
+  for (int k = 0; k < 2; k++)
+    for (int l = 1; l < nlevels; l++) {
+      lv_off[k][l] = off;
+      off += ((size_t)lp[l] * lh[l] + 16 + 255) & ~(size_t)255;
+    }
+  if (off > VSF_NOALLOC_SCRATCH_BYTES) return VSF_E_CAPACITY;  // frame too large for the 4 MiB array (about 5.9 Mpixel)
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return VSF_E_HIP;
+  if (dev != p->device_id && hipSetDevice(p->device_id) != hipSuccess) return VSF_E_HIP;
+  uint8_t* base = nullptr;
+  int rc = noalloc_scratch_ptr(p->device_id, &base);
+  if (rc) return rc;
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  uint8_t* lv[2][MAXL] = {};
+  for (int k = 0; k < 2; k++)
+    for (int l = 1; l < nlevels; l++) lv[k][l] = base + lv_off[k][l];
+  const FrameRef fr[2] = {{d_prev, (long long)prev_stride * p->height, prev_stride},
+                          {d_next, (long long)next_stride * p->height, next_stride}};
+  PyrView V[2];
+  for (int k = 0; k < 2; k++) {
+    launch_pyramid(fr[k], lv[k], nlevels, lw, lh, lp, 1, s);
+    memset(&V[k], 0, sizeof(PyrView));
+    V[k].nlevels = nlevels;
+    for (int l = 0; l < nlevels; l++) {
+      V[k].w[l] = lw[l];
+      V[k].h[l] = lh[l];
+      V[k].base[l] = l ? lv[k][l] : fr[k].ptr;
+      V[k].sstride[l] = l ? (long long)lp[l] * lh[l] : fr[k].sstride;
+      V[k].pitch[l] = l ? lp[l] : fr[k].pitch;
+    }
+  }
+  const LkParams lk = make_lk_params(p);
+  const LkSmem lks = lk_smem_layout(lk.win, lk.jmargin);
+#define VSF_LAUNCH_NP(SEG)                                                                                   \
+  hipLaunchKernelGGL(lk_points_kernel<SEG>, dim3(n), dim3(64), lks.total, s, V[0], V[1],                      \
+                     reinterpret_cast<const float2*>(d_prev_pts), n, lk, reinterpret_cast<float2*>(d_next_pts), \
+                     d_status)
+  switch (lk_seg_template(lk.seglen)) {
+    case 7: VSF_LAUNCH_NP(7); break;
+    case 8: VSF_LAUNCH_NP(8); break;
+    default: VSF_LAUNCH_NP(16); break;
+  }
+#undef VSF_LAUNCH_NP
+  return hipGetLastError() == hipSuccess ? VSF_OK : VSF_E_HIP;
 }
 
 // ------------------------------------------------------------------------------------------------
