@@ -65,7 +65,10 @@ def test_bad_parameters_rejected(vsf):
     lib = vsf.lib()
     h = C.c_void_p()
     for kw in ({"klt_win": 40}, {"klt_win": 2}, {"streams": 0}, {"width": 10, "height": 10}, {"block_size": 5},
-               {"klt_max_level": 9}, {"grid_rows": 0}):
+               {"klt_max_level": 9}, {"grid_rows": 0}, {"quality_level": 1.5}, {"quality_level": -0.1},
+               {"width": 65536, "height": 16384},                                  # 32-bit raster indices
+               {"detector_kind": 1, "anms_quality_level": 2.0},
+               {"detector_kind": 1, "width": 32000, "height": 32000}):              # ANMS tile count above grid.y
         p = vsf.default_params(**kw)
         assert lib.vsf_create(C.byref(p), C.byref(h)) == vsf.VSF_E_INVALID
     assert lib.vsf_create(None, C.byref(h)) == vsf.VSF_E_INVALID

@@ -180,3 +180,24 @@ def test_candidate_overflow_path_is_exact(vsf, oracle, synth):
         odet.update_detection(T, noisy[k])
         assert db.as_dict() == T.as_dict() and db.n >= 60
         db.n = T.n.value = db.n // 2   # make room so that the second frame detects again
+
+
+def test_refused_configurations(vsf):
+    """Configurations whose kernels could not launch are refused at context creation, not at the first call."""
+    import ctypes as C
+    lib = vsf.lib()
+    h = C.c_void_p()
+    for kw in ({"max_features": 60000, "grid_rows": 1, "grid_cols": 8},    # append_kernel's LDS slots
+               {"max_features": 70000, "grid_rows": 3, "grid_cols": 3}):   # per-cell quota above 8192
+        p = vsf.default_params(**kw)
+        assert lib.vsf_create(C.byref(p), C.byref(h)) == vsf.VSF_E_INVALID, kw
+    # a large context and then a small one: the earlier context still launches with its larger dynamic LDS
+    # (select_kernel keeps 15104 keys = 120 KB for a 376x240 cell, 2048 keys for the small context's)
+    big = vsf.Context(vsf.default_params(width=752, height=480, grid_rows=2, grid_cols=2, max_features=400))
+    small = vsf.Context(vsf.default_params(width=64, height=48, grid_rows=1, grid_cols=1, max_features=8, klt_win=9))
+    from _pkg import load_synth
+    img = load_synth().sequence(3, 752, 480, 1)[0][0]
+    ids, xy, age = np.zeros(512, np.uint64), np.zeros((512, 2)), np.zeros(512, np.uint32)
+    assert big.detect(img, ids, xy, age, 0) > 200
+    small.close()
+    big.close()

@@ -124,17 +124,20 @@ __global__ __launch_bounds__(256) void anms_topk_kernel(const float* __restrict_
   const unsigned long long* C = cand + (long long)stream * ap.cand_cap;
   const unsigned int enc = cell_max[stream];
   const float thr = (float)((enc ? (double)float_order_decode(enc) : 0.0) * ap.quality);
-  auto key_at = [&](int i) -> unsigned long long { return overflow ? anms_key_from_map(L, ap.w, ap.h, thr, F, i) : C[i]; };
+  // the list holds every positive local maximum the score kernel could not rule out: cv's threshold is applied here
+  auto key_at = [&](int i) -> unsigned long long {
+    if (overflow) return anms_key_from_map(L, ap.w, ap.h, thr, F, i);
+    const unsigned long long k = C[i];
+    return __uint_as_float((unsigned int)(k >> 32)) > thr ? k : 0ull;
+  };
 
   // number of candidates (the list length, or a count over the map)
   if (threadIdx.x == 0) s_count = 0;
   __syncthreads();
-  if (overflow) {
+  {
     int c = 0;
     for (int i = threadIdx.x; i < M; i += 256) c += key_at(i) != 0ull;
-    atomicAdd(&s_count, c);
-  } else if (threadIdx.x == 0) {
-    s_count = total;
+    if (c) atomicAdd(&s_count, c);
   }
   __syncthreads();
   const int ncand = s_count;

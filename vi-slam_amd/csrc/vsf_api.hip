@@ -412,18 +412,18 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
     hipLaunchKernelGGL(occupancy_kernel, dim3(streams), dim3(256), sm, s, c->d_xy, c->d_n, c->cap, G, W, H,
                        c->hash_size, c->d_need, c->d_nact, c->d_cellmax, c->d_candcnt);
   }
-  const int tiles_x = (c->max_cw + SC_TW - 1) / SC_TW, tiles_y = (c->max_ch + SC_TH - 1) / SC_TH;
+  const int tiles_x = sc_tiles(c->max_cw, SC_IW), tiles_y = sc_tiles(c->max_ch, SC_IH);
   {
     ProfScope prof(c, VSF_K_SCORE, s);
-    hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y, c->ncell, streams), dim3(256), 0, s, f.ptr, f.sstride,
-                       f.pitch, W, H, masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, c->k_side, c->k_mid,
-                       c->d_lam, c->d_cellmax);
+    hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y * c->ncell, streams), dim3(256), 0, s, f.ptr, f.sstride,
+                       f.pitch, W, H, masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, tiles_y, c->k_side,
+                       c->k_mid, c->p.quality_level, c->d_cellmax, c->d_cand, c->cand_cap, c->d_candcnt, 0);
   }
-  {
+  {  // cells whose candidate list overflowed (rare): their lambda map, for select_kernel's exact fallback
     ProfScope prof(c, VSF_K_CANDIDATES, s);
-    hipLaunchKernelGGL(candidate_kernel, dim3(tiles_x * tiles_y, c->ncell, streams), dim3(256), 0, s, c->d_lam, G,
-                       c->d_nact, tiles_x, c->d_cellmax, c->p.quality_level, masks, mask_sstride, mask_pitch,
-                       c->d_cand, c->cand_cap, c->d_candcnt, 0);
+    hipLaunchKernelGGL(lam_fill_kernel<3>, dim3(c->ncell, streams), dim3(256), 0, s, f.ptr, f.sstride, f.pitch, W, H,
+                       masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, tiles_y, c->k_side, c->k_mid, c->d_lam,
+                       c->d_cellmax, c->d_candcnt, c->cand_cap, -1);
   }
   {
     ProfScope prof(c, VSF_K_SELECT, s);
@@ -471,23 +471,29 @@ int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long l
     hipLaunchKernelGGL(anms_disc_kernel, dim3(streams), dim3(256), 0, s, c->d_xy, c->d_n, c->cap, ap, c->d_aflag,
                        c->d_cellmax, c->d_candcnt);
   }
-  const int tiles_x = (W + SC_TW - 1) / SC_TW, tiles_y = (H + SC_TH - 1) / SC_TH;
+  const int tiles_x = sc_tiles(W, SC_IW), tiles_y = sc_tiles(H, SC_IH);
   const long long fsz = (long long)W * H;
   {
     ProfScope prof(c, VSF_K_SCORE, s);
     if (c->p.anms_block_size == 4)
-      hipLaunchKernelGGL(score_kernel<4>, dim3(tiles_x * tiles_y, 1, streams), dim3(256), 0, s, f.ptr, f.sstride,
-                         f.pitch, W, H, c->d_aflag, fsz, W, G, c->d_anact, tiles_x, c->ak_side, c->ak_mid, c->d_lam,
-                         c->d_cellmax);
+      hipLaunchKernelGGL(score_kernel<4>, dim3(streams, tiles_x * tiles_y), dim3(256), 0, s, f.ptr, f.sstride, f.pitch,
+                         W, H, c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, ap.quality,
+                         c->d_cellmax, c->d_acand, ap.cand_cap, c->d_candcnt, 1);
     else
-      hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y, 1, streams), dim3(256), 0, s, f.ptr, f.sstride,
-                         f.pitch, W, H, c->d_aflag, fsz, W, G, c->d_anact, tiles_x, c->ak_side, c->ak_mid, c->d_lam,
-                         c->d_cellmax);
+      hipLaunchKernelGGL(score_kernel<3>, dim3(streams, tiles_x * tiles_y), dim3(256), 0, s, f.ptr, f.sstride, f.pitch,
+                         W, H, c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, ap.quality,
+                         c->d_cellmax, c->d_acand, ap.cand_cap, c->d_candcnt, 1);
   }
   {
     ProfScope prof(c, VSF_K_CANDIDATES, s);
-    hipLaunchKernelGGL(candidate_kernel, dim3(streams, 1, tiles_x * tiles_y), dim3(256), 0, s, c->d_lam, G, c->d_anact,
-                       tiles_x, c->d_cellmax, ap.quality, c->d_aflag, fsz, W, c->d_acand, ap.cand_cap, c->d_candcnt, 1);
+    if (c->p.anms_block_size == 4)
+      hipLaunchKernelGGL(lam_fill_kernel<4>, dim3(1, streams), dim3(256), 0, s, f.ptr, f.sstride, f.pitch, W, H,
+                         c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, c->d_lam,
+                         c->d_cellmax, c->d_candcnt, ap.cand_cap, -1);
+    else
+      hipLaunchKernelGGL(lam_fill_kernel<3>, dim3(1, streams), dim3(256), 0, s, f.ptr, f.sstride, f.pitch, W, H,
+                         c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, c->d_lam,
+                         c->d_cellmax, c->d_candcnt, ap.cand_cap, -1);
   }
   {
     ProfScope prof(c, VSF_K_SELECT, s);
@@ -505,6 +511,18 @@ int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long l
   }
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
+}
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is per kernel and process-wide: keep the running maximum.
+hipError_t raise_dynamic_lds(const void* fn, int slot, int bytes) {
+  static std::mutex mu;
+  static int cur[8] = {};
+  if (bytes <= 48 * 1024) return hipSuccess;
+  std::lock_guard<std::mutex> lock(mu);
+  if (bytes <= cur[slot]) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e == hipSuccess) cur[slot] = bytes;
+  return e;
 }
 
 // ref: FeatureDetectorShiTomasiBucketing.cpp:13-36 (GenerateGrid) and :144-149 (Rect2f -> Rect)
@@ -680,7 +698,10 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   // the LK window must fit the frame; an LSSD context never runs the LK kernels
   if (p->tracker_kind != VSF_TRACKER_LSSD && (p->width <= p->klt_win || p->height <= p->klt_win)) return VSF_E_INVALID;
   if (p->grid_rows < 1 || p->grid_cols < 1 || p->max_features < 0 || p->block_size != 3) return VSF_E_INVALID;
-  if (!(p->min_distance >= 0.0) || !(p->quality_level >= 0.0)) return VSF_E_INVALID;
+  // quality in [0, 1]: cv accepts more, but a threshold above the maximum keeps nothing, and the fused score kernel's
+  // "local maximum first, threshold later" is equivalent to cv's order only in this range (vsf_kernels.hpp)
+  if (!(p->min_distance >= 0.0) || !(p->quality_level >= 0.0) || p->quality_level > 1.0) return VSF_E_INVALID;
+  if ((long long)p->width * p->height > 0x7fffffffLL / 4) return VSF_E_INVALID;  // 32-bit raster / map indices
   const bool use_anms = p->detector_kind == VSF_DETECTOR_ANMS;
   if (p->detector_kind != VSF_DETECTOR_BUCKETING && !use_anms) return VSF_E_INVALID;
   int anms_k = 0;
@@ -689,8 +710,11 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     if (anms_k < 1 || anms_k > 2048 || (int)p->min_distance > ANMS_MAX_RADIUS || (int)p->min_distance < 0)
       return VSF_E_INVALID;
     if (p->anms_block_size != 3 && p->anms_block_size != 4) return VSF_E_INVALID;
-    if (!(p->anms_quality_level >= 0.0) || !(p->anms_tolerance >= 0.0) || p->anms_ignore_edge < 0) return VSF_E_INVALID;
+    if (!(p->anms_quality_level >= 0.0) || p->anms_quality_level > 1.0 || !(p->anms_tolerance >= 0.0) ||
+        p->anms_ignore_edge < 0)
+      return VSF_E_INVALID;
     if (p->width > 32767 || p->height > 32767) return VSF_E_INVALID;  // keypoints travel as short2
+    if ((long long)sc_tiles(p->width, SC_IW) * sc_tiles(p->height, SC_IH) > 65535) return VSF_E_INVALID;  // grid.y
   }
   const bool use_lssd = p->tracker_kind == VSF_TRACKER_LSSD;
   if (p->tracker_kind != VSF_TRACKER_LK && !use_lssd) return VSF_E_INVALID;
@@ -756,6 +780,12 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     delete c;
     return VSF_E_INVALID;
   }
+  // append_kernel keeps one slot per selectable corner in LDS
+  if ((size_t)(c->ncell + 1 + (size_t)c->ncell * (c->grid_max > 0 ? c->grid_max : 1)) * 4 > 150 * 1024 ||
+      (use_anms && (size_t)(2 + 2 * (size_t)anms_k) * 4 > 150 * 1024)) {
+    delete c;
+    return VSF_E_INVALID;
+  }
   {
     const double scale = 1.0 / ((double)(1 << 2) * p->block_size * 255.0);  // cv: cornerEigenValsVecs
     c->k_side = (float)(1.0 * scale);
@@ -786,7 +816,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     a.hash_size = 2 * a.kcap;
     a.hash_bits = 0;
     while ((1 << a.hash_bits) < a.hash_size) a.hash_bits++;
-    a.cand_cap = (p->width * p->height) / 8;
+    a.cand_cap = (p->width * p->height) / 6;
     if (a.cand_cap < 4096) a.cand_cap = 4096;
     a.quality = p->anms_quality_level;
     {  // cv::Circle (drawing.cpp), fill: midpoint walk; span on rows +-dy is +-dx and on rows +-dx is +-dy
@@ -878,19 +908,16 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     acc(hipMemcpy(c->d_rects, rects.data(), rects.size() * sizeof(int4), hipMemcpyHostToDevice));
     acc(hipMemcpy(c->d_origin, origin.data(), origin.size() * sizeof(float2), hipMemcpyHostToDevice));
     acc(hipMemcpy(c->d_lam_off, lam_off.data(), lam_off.size() * sizeof(int), hipMemcpyHostToDevice));
-    // dynamic LDS above the default limit needs an explicit opt-in
+    // dynamic LDS above the default limit needs an explicit opt-in; the attribute belongs to the kernel, not to
+    // the context, so only ever raise it (an earlier, larger context still launches with its own size)
     const int occ_sm = (c->hash_size + c->ncell) * 4;
-    if (occ_sm > 48 * 1024)
-      acc(hipFuncSetAttribute(reinterpret_cast<const void*>(occupancy_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, occ_sm));
     const int sel_sm = c->cand_cap * 8 + (c->grid_max > 0 ? c->grid_max : 1) * 12;
-    if (sel_sm > 48 * 1024)
-      acc(hipFuncSetAttribute(reinterpret_cast<const void*>(select_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, sel_sm));
-    const int app_sm = (c->ncell + 1 + c->ncell * (c->grid_max > 0 ? c->grid_max : 1)) * 4;
-    if (app_sm > 48 * 1024)
-      acc(hipFuncSetAttribute(reinterpret_cast<const void*>(append_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, app_sm));
+    int app_sm = (c->ncell + 1 + c->ncell * (c->grid_max > 0 ? c->grid_max : 1)) * 4;
+    if (use_anms && (2 + c->anms.kcap) * 4 > app_sm) app_sm = (2 + c->anms.kcap) * 4;
+    acc(raise_dynamic_lds(reinterpret_cast<const void*>(occupancy_kernel), 0, occ_sm));
+    acc(raise_dynamic_lds(reinterpret_cast<const void*>(select_kernel), 1, sel_sm));
+    acc(raise_dynamic_lds(reinterpret_cast<const void*>(append_kernel), 2, app_sm));
+    if (use_anms) acc(raise_dynamic_lds(reinterpret_cast<const void*>(anms_ssc_kernel), 3, anms_ssc_smem(c->anms)));
     if (use_anms) {
       const int4 r = make_int4(0, 0, p->width, p->height);
       const float2 o = make_float2(0.f, 0.f);
@@ -900,14 +927,6 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
       acc(hipMemcpy(c->d_aorigin, &o, sizeof(o), hipMemcpyHostToDevice));
       acc(hipMemcpy(c->d_alamoff, lo, sizeof(lo), hipMemcpyHostToDevice));
       acc(hipMemcpy(c->d_anact, ones.data(), (size_t)B * 4, hipMemcpyHostToDevice));
-      const int ssc_sm = anms_ssc_smem(c->anms);
-      if (ssc_sm > 48 * 1024)
-        acc(hipFuncSetAttribute(reinterpret_cast<const void*>(anms_ssc_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, ssc_sm));
-      const int aapp_sm = (2 + c->anms.kcap) * 4;
-      if (aapp_sm > app_sm && aapp_sm > 48 * 1024)
-        acc(hipFuncSetAttribute(reinterpret_cast<const void*>(append_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, aapp_sm));
     }
     if (e != hipSuccess) rc = VSF_E_HIP;
   }
@@ -1198,24 +1217,15 @@ int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
   HIPCHK(c, hipSetDevice(c->p.device_id));
   rc = upload_frame(c, c->det_frame, img, w, h, stride);
   if (rc) return rc;
-  // all cells active: run occupancy on an empty table, then force n_active = ncell
-  int zero = 0;
-  int saved_n = 0;
-  HIPCHK(c, hipMemcpy(&saved_n, c->d_n, 4, hipMemcpyDeviceToHost));
-  HIPCHK(c, hipMemcpy(c->d_n, &zero, 4, hipMemcpyHostToDevice));
   const GridView G = grid_view(c);
-  const size_t sm = (size_t)(c->hash_size + c->ncell) * sizeof(int);
-  hipLaunchKernelGGL(occupancy_kernel, dim3(1), dim3(256), sm, nullptr, c->d_xy, c->d_n, c->cap, G, w, h,
-                     c->hash_size, c->d_need, c->d_nact, c->d_cellmax, c->d_candcnt);
-  HIPCHK(c, hipMemcpy(c->d_nact, &c->ncell, 4, hipMemcpyHostToDevice));
-  const int tiles_x = (c->max_cw + SC_TW - 1) / SC_TW, tiles_y = (c->max_ch + SC_TH - 1) / SC_TH;
+  const int tiles_x = sc_tiles(c->max_cw, SC_IW), tiles_y = sc_tiles(c->max_ch, SC_IH);
   const FrameRef f = own_ref(c, c->det_frame);
-  hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y, c->ncell, 1), dim3(256), 0, nullptr, f.ptr, f.sstride,
-                     f.pitch, w, h, (const uint8_t*)nullptr, 0ll, 0, G, c->d_nact, tiles_x, c->k_side, c->k_mid,
-                     c->d_lam, c->d_cellmax);
+  // the map of this one cell through the score kernels' own tile routine; the feature table is not touched
+  hipLaunchKernelGGL(lam_fill_kernel<3>, dim3(c->ncell, 1), dim3(256), 0, nullptr, f.ptr, f.sstride, f.pitch, w, h,
+                     (const uint8_t*)nullptr, 0ll, 0, G, c->d_nact, tiles_x, tiles_y, c->k_side, c->k_mid, c->d_lam,
+                     c->d_cellmax, c->d_candcnt, c->cand_cap, cell);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(nullptr));
-  HIPCHK(c, hipMemcpy(c->d_n, &saved_n, 4, hipMemcpyHostToDevice));
   std::vector<int4> rects(c->ncell);
   std::vector<int> off(c->ncell + 1);
   HIPCHK(c, hipMemcpy(rects.data(), c->d_rects, rects.size() * sizeof(int4), hipMemcpyDeviceToHost));

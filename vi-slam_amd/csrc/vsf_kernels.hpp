@@ -1284,39 +1284,68 @@ __device__ __forceinline__ float float_order_decode(unsigned int e) {
   return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
 }
 
-// Min-eigenvalue map of one grid cell tile (cv::cornerMinEigenVal on the cell ROI of the parent
-// image) + masked per-cell maximum.  Block = 64x16 pixels of one cell.
-// Sobel reads the parent image's real pixels (REFLECT_101 only at the true image border); the box
-// filter reflects at the CELL border and sums in double like cv::boxFilter does for 32F input.
-constexpr int SC_TW = 64, SC_TH = 16;
+// Min-eigenvalue score of one grid cell tile (cv::cornerMinEigenVal on the cell ROI of the parent image;
+// SURVEY A.1 steps 1-4), the masked per-cell maximum, AND the candidate corners of the tile (steps 5-6), in one
+// pass over the frame: the lambda map is never written to memory.
+//   * A block computes lambda on a 64x16 block of cell positions and emits candidates from its inner 62x14
+//     (every candidate's 3x3 neighbourhood lies inside the block); tiles step by 62 x 14.
+//   * cv thresholds the map at quality * max and then keeps pixels equal to their 3x3 dilation.  The threshold is
+//     not known before every tile of the cell has been scored, but it commutes with the local-maximum test: for
+//     quality in [0, 1] a surviving pixel has lambda > thr >= 0, every neighbour the threshold zeroes is below it,
+//     and the others keep their value, so "thresholded pixel equals its thresholded dilation" <=> "lambda > thr
+//     and lambda >= its eight neighbours".  The block therefore emits a key for every positive 3x3 local maximum
+//     (interior ring, mask) and select_kernel / anms_topk_kernel apply `lambda > thr` when they read the list.
+//     Keys at or below quality * (the cell maximum seen SO FAR: an atomic read at block start joined with the
+//     block's own maximum, a lower bound of the final one) can never pass and are dropped at once.
+//   * Sobel reads the parent image's real pixels (REFLECT_101 only at the true image border); the box filter
+//     reflects at the CELL border and sums in double like cv::boxFilter does for 32F input.
+constexpr int SC_TW = 64, SC_TH = 16;          // lambda block of a tile
+constexpr int SC_IW = SC_TW - 2, SC_IH = SC_TH - 2;  // candidate positions of a tile (tile step)
 constexpr int SC_IP = 80;  // LDS pitch of the staged 8-bit tile (tile width + up to 3 bytes of dword alignment)
+constexpr int SC_LP = SC_TW + 1;               // LDS pitch of the lambda block
+constexpr int SC_LCAP = SC_IH * SC_IW / 4 + 64;  // keys gathered in LDS per block; beyond it they go straight to the list
+
+__host__ __device__ inline int sc_tiles(int cells_extent, int step) {  // tiles covering positions -1 .. extent
+  const int t = (cells_extent - 1 + step - 1) / step;
+  return t > 1 ? t : 1;
+}
 
 // BS = blockSize of the box filter: 3 (offsets -1..+1; cv::goodFeaturesToTrack default, the bucketing
 // detector) or 4 (offsets -2..+1: anchor = blockSize / 2; the ANMS detector's GFTTDetector).
-template <int BS>
-__global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
-                                                    int row_stride, int w, int h,
-                                                    const uint8_t* __restrict__ masks, long long mask_sstride,
-                                                    int mask_row_stride, GridView G,
-                                                    const int* __restrict__ n_active, int tiles_x,
-                                                    float k_side, float k_mid, float* __restrict__ lam,
-                                                    unsigned int* __restrict__ cell_max) {
+// WRITE_LAM: also store the lambda block to the cell's map (fallback / debug); EMIT: emit candidate keys.
+template <int BS, bool WRITE_LAM, bool EMIT>
+__device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int row_stride, int w, int h,
+                                           const uint8_t* __restrict__ M, int mask_row_stride, int4 rc, int tx, int ty,
+                                           float k_side, float k_mid, float* __restrict__ lam_cell,
+                                           unsigned int* __restrict__ cmax, double quality,
+                                           unsigned long long* __restrict__ cand, int cand_cap,
+                                           int* __restrict__ ccnt) {
   constexpr int HL = BS / 2, HR = BS - 1 - HL;             // covariance halo left/top, right/bottom
   constexpr int CW = SC_TW + HL + HR, CH = SC_TH + HL + HR;  // covariance tile
   constexpr int IW = CW + 2, IH = CH + 2;                  // staged 8-bit tile (Sobel reads +-1 more)
   static_assert(IW + 3 <= SC_IP && SC_IP % 4 == 0, "tile pitch");
-  __shared__ __align__(16) uint8_t s_img[IH * SC_IP];
-  __shared__ float s_cov[3][CH * CW];  // dx*dx, dx*dy, dy*dy: float32 products, as cv computes them
+  // LDS: the staged image is dead once the covariances exist, and those once lambda exists; the mask bits and
+  // the gathered keys reuse their space (the kernel runs on occupancy: three barriers and dependent LDS round
+  // trips per tile, 8 blocks per CU at 20 KB each)
+  constexpr int IMG_BYTES = (IH * SC_IP + 15) & ~15, COV_BYTES = 3 * CH * CW * 4;
+  static_assert(SC_TH * SC_TW <= IMG_BYTES && SC_LCAP * 8 <= COV_BYTES, "aliased regions");
+  __shared__ __align__(16) uint8_t s_raw[IMG_BYTES + COV_BYTES];
+  __shared__ float s_lam[EMIT ? SC_TH * SC_LP : 1];
+  uint8_t* s_img = s_raw;
+  uint8_t* s_msk = s_raw;                                                         // after the covariance stage
+  float(*s_cov)[CH * CW] = reinterpret_cast<float(*)[CH * CW]>(s_raw + IMG_BYTES);  // dx*dx, dx*dy, dy*dy (float32 products, as cv)
+  unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw + IMG_BYTES);  // after the lambda stage
   __shared__ unsigned int s_max;
-  const int stream = blockIdx.z, cell = blockIdx.y;
-  if (cell >= n_active[stream]) return;
-  const int4 rc = G.rects[cell];
+  __shared__ int s_n, s_base;
   const int cw = rc.z, ch = rc.w;
-  const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-  const int cx0 = tx * SC_TW, cy0 = ty * SC_TH;  // tile origin in cell coordinates
-  if (cx0 >= cw || cy0 >= ch) return;
-  const uint8_t* F = frames + (long long)stream * frame_sstride;
-  if (threadIdx.x == 0) s_max = 0u;
+  const int cx0 = tx * SC_IW - 1, cy0 = ty * SC_IH - 1;  // origin of the lambda block in cell coordinates
+  if (cx0 + 1 >= cw || cy0 + 1 >= ch) return;            // block-uniform: the tile lies outside this cell
+  unsigned int seen = 0u;
+  if (EMIT) seen = __hip_atomic_load(cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    s_max = 0u;
+    s_n = 0;
+  }
   // staged image tile: parent coords [rc.x + cx0 - HL - 1, +IW) x [rc.y + cy0 - HL - 1, +IH)
   const int gx0 = rc.x + cx0 - HL - 1, gy0 = rc.y + cy0 - HL - 1;
   // tiles away from the image border are fetched as aligned dwords (sh = bytes of alignment slack);
@@ -1341,45 +1370,76 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
     }
   }
   __syncthreads();
-  // covariance at cell coords [cx0-HL, cx0+SC_TW+HR) x [cy0-HL, cy0+SC_TH+HR) that lie inside the cell
-  for (int i = threadIdx.x; i < CH * CW; i += 256) {
-    const int y = i / CW, x = i - y * CW;
-    const int cx = cx0 - HL + x, cy = cy0 - HL + y;
-    float vxx = 0, vxy = 0, vyy = 0;
-    if (cx >= 0 && cx < cw && cy >= 0 && cy < ch) {
-      const uint8_t* c = s_img + (y + 1) * SC_IP + (sh + x + 1);
-      const int p = SC_IP;
-      const float r_m = (float)((int)c[-p + 1] - (int)c[-p - 1]);
-      const float r_0 = (float)((int)c[1] - (int)c[-1]);
-      const float r_p = (float)((int)c[p + 1] - (int)c[p - 1]);
-      const float dx = (r_m + r_p) * k_side + r_0 * k_mid;
-      float s_m = k_side * (float)c[-p - 1];
-      s_m += k_mid * (float)c[-p];
-      s_m += k_side * (float)c[-p + 1];
-      float s_p = k_side * (float)c[p - 1];
-      s_p += k_mid * (float)c[p];
-      s_p += k_side * (float)c[p + 1];
-      const float dy = s_p - s_m;
-      vxx = dx * dx;
-      vxy = dx * dy;
-      vyy = dy * dy;
+  // covariance at cell coords [cx0-HL, cx0+SC_TW+HR) x [cy0-HL, cy0+SC_TH+HR) that lie inside the cell.
+  // A thread walks one column of the tile down a strip of RS rows: per image row it forms the horizontal
+  // difference r = I(x+1) - I(x-1) and the horizontal smooth s = k I(x-1) + 2k I(x) + k I(x+1) ONCE, and every
+  // covariance row combines three consecutive (r, s) pairs -- the same float operations in the same order as
+  // the direct 3x3 form, a third of the conversions and multiplies.
+  {
+    constexpr int RS = (CH + 2) / 3;
+    static_assert(3 * CW <= 256 && 3 * RS >= CH, "strip mapping of the covariance stage");
+    const int t = threadIdx.x;
+    const int strip = (t >= CW ? 1 : 0) + (t >= 2 * CW ? 1 : 0);
+    const int x = t - strip * CW;
+    if (t < 3 * CW) {
+      const int y0 = strip * RS;
+      const uint8_t* col = s_img + (sh + x);
+      auto rowvals = [&](int iy, float& rr, float& ss) {
+        const uint8_t* c = col + iy * SC_IP;
+        const float f0 = (float)c[0], f1 = (float)c[1], f2 = (float)c[2];
+        rr = f2 - f0;  // exact: equals (float)(int difference)
+        float sv = k_side * f0;
+        sv += k_mid * f1;
+        sv += k_side * f2;
+        ss = sv;
+      };
+      float r0, s0, r1, s1;
+      rowvals(y0, r0, s0);
+      rowvals(y0 + 1, r1, s1);
+      const int cx = cx0 - HL + x;
+      const bool xin = cx >= 0 && cx < cw;
+#pragma unroll
+      for (int k = 0; k < RS; k++) {
+        const int y = y0 + k;
+        if (y < CH) {
+          float r2, s2;
+          rowvals(y + 2, r2, s2);
+          const float dx = (r0 + r2) * k_side + r1 * k_mid;
+          const float dy = s2 - s0;
+          const int cy = cy0 - HL + y;
+          const bool in = xin && cy >= 0 && cy < ch;
+          s_cov[0][y * CW + x] = in ? dx * dx : 0.f;
+          s_cov[1][y * CW + x] = in ? dx * dy : 0.f;
+          s_cov[2][y * CW + x] = in ? dy * dy : 0.f;
+          r0 = r1;
+          s0 = s1;
+          r1 = r2;
+          s1 = s2;
+        }
+      }
     }
-    s_cov[0][i] = vxx;
-    s_cov[1][i] = vxy;
-    s_cov[2][i] = vyy;
   }
   __syncthreads();
-  const uint8_t* M = masks ? masks + (long long)stream * mask_sstride : nullptr;
-  float* lam_cell = lam + (long long)stream * G.lam_total + G.lam_off[cell];
   unsigned int local_max = 0u;
-  auto finish = [&](int cx, int cy, const double (&sum)[3]) {
+  const float thr_seen = (EMIT && seen) ? (float)((double)float_order_decode(seen) * quality) : -INFINITY;
+  // (x, y): position inside the lambda block; (cx, cy) = (cx0 + x, cy0 + y) lies inside the cell
+  auto finish = [&](int x, int y, const double (&sum)[3]) {
+    const int cx = cx0 + x, cy = cy0 + y;
     const float a = (float)sum[0] * 0.5f, b = (float)sum[1], c = (float)sum[2] * 0.5f;
-    const float lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-    lam_cell[cy * cw + cx] = lm;
-    if (!M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)]) {
-      const unsigned int e = float_order_encode(lm);
-      local_max = max(local_max, e);
+    // lambda <= a + c.  Where a + c is not above quality * (the cell maximum seen at block start) the pixel passes
+    // neither the final threshold nor the maximum, and as a neighbour any value below a surviving candidate's
+    // (which is above that bound) decides the same: 0 stands in, and the correctly rounded square root (a dozen
+    // instructions) is skipped -- for whole waves in smooth regions.
+    float lm = 0.f;
+    const bool full = WRITE_LAM || a + c > thr_seen;
+    if (full) lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+    if (WRITE_LAM) lam_cell[cy * cw + cx] = lm;
+    const bool mk = !M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)];
+    if (EMIT) {
+      s_lam[y * SC_LP + x] = lm;
+      s_msk[y * SC_TW + x] = mk ? 1 : 0;
     }
+    if (mk && full) local_max = max(local_max, float_order_encode(lm));
   };
   // Box filter in double like cv::boxFilter for 32F input: row sum left to right, then the column of
   // row sums top to bottom.
@@ -1410,13 +1470,13 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
 #pragma unroll
         for (int j = 1; j < BS; j++) sum[q] += rs[q][o + j];
       }
-      finish(cx0 + x, cy0 + y0 + o, sum);
+      finish(x, y0 + o, sum);
     }
   } else {
     for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
       const int y = i / SC_TW, x = i - y * SC_TW;
       const int cx = cx0 + x, cy = cy0 + y;
-      if (cx < cw && cy < ch) {
+      if (cx >= 0 && cx < cw && cy >= 0 && cy < ch) {
         int xi[BS];
 #pragma unroll
         for (int q = 0; q < BS; q++) xi[q] = reflect101(cx - HL + q, cw) - (cx0 - HL);
@@ -1433,7 +1493,7 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
             sum[q] = (j == 0) ? t : sum[q] + t;
           }
         }
-        finish(cx, cy, sum);
+        finish(x, y, sum);
       }
     }
   }
@@ -1441,100 +1501,104 @@ __global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ 
   for (int m = 32; m >= 1; m >>= 1) local_max = max(local_max, (unsigned int)__shfl_xor((int)local_max, m, 64));
   if ((threadIdx.x & 63) == 0 && local_max) atomicMax(&s_max, local_max);
   __syncthreads();
-  if (threadIdx.x == 0 && s_max) atomicMax(&cell_max[stream * G.ncell + cell], s_max);
-}
-
-// Threshold at quality*max, 3x3 local maximum, interior of the cell only;
-// survivors are appended to the cell's candidate list as keys (lambda bits << 32 | raster index),
-// whose unsigned order is exactly cv's greaterThanPtr order (value, then address).
-__global__ __launch_bounds__(256) void candidate_kernel(const float* __restrict__ lam, GridView G,
-                                                        const int* __restrict__ n_active, int tiles_x,
-                                                        const unsigned int* __restrict__ cell_max, double quality,
-                                                        const uint8_t* __restrict__ masks, long long mask_sstride,
-                                                        int mask_row_stride, unsigned long long* __restrict__ cand,
-                                                        int cand_cap, int* __restrict__ cand_cnt,
-                                                        int stream_major) {
-  // stream_major (the ANMS detector's single whole-frame cell): grid = (streams, 1, tiles), so that the blocks in
-  // flight belong to many streams.  Every block ends with one returning atomic on its cell's counter; with the
-  // tiles of ONE cell in flight together (grid = (tiles, cells, streams)) a few hundred blocks queue on a handful
-  // of addresses and the kernel runs at the L2's same-address atomic rate (1.67 ms per 1024 frames, measured).
-  const int stream = stream_major ? blockIdx.x : blockIdx.z, cell = blockIdx.y;
-  const int tile = stream_major ? blockIdx.z : blockIdx.x;
-  if (cell >= n_active[stream]) return;
-  const int4 rc = G.rects[cell];
-  const int cw = rc.z, ch = rc.w;
-  const int tx = tile % tiles_x, ty = tile / tiles_x;
-  const int cx0 = tx * SC_TW, cy0 = ty * SC_TH;
-  if (cx0 >= cw || cy0 >= ch) return;
-  const unsigned int enc = cell_max[stream * G.ncell + cell];
-  const double maxVal = enc ? (double)float_order_decode(enc) : 0.0;
-  const float thr = (float)(maxVal * quality);
-  const float* L = lam + (long long)stream * G.lam_total + G.lam_off[cell];
-  const uint8_t* M = masks ? masks + (long long)stream * mask_sstride : nullptr;
-  // thresholded lambda tile (+1 halo) in LDS; survivors are gathered in LDS too, and ONE global atomic
-  // per block reserves their slots in the cell's list (the order inside the list does not matter)
-  constexpr int LW = SC_TW + 2, LH = SC_TH + 2;
-  constexpr int LCAP = SC_TH * SC_TW / 4 + 64;  // beyond it (plateaus of equal values) keys go straight to the list
-  __shared__ float s_lam[LH * LW];
-  __shared__ unsigned long long s_keys[LCAP];
-  __shared__ int s_n, s_base;
-  if (threadIdx.x == 0) s_n = 0;
-  // the mask bytes of this thread's four pixels, fetched up front together with the lambda tile: read inside
-  // the survivor branch they are four dependent global round trips per thread
-  unsigned int mk[SC_TH * SC_TW / 256];
+  const unsigned int blk_max = s_max;
+  if (threadIdx.x == 0 && blk_max) atomicMax(cmax, blk_max);
+  if (!EMIT) return;
+  // ---- candidates of the inner 62 x 14 positions
+  const unsigned int lb = max(seen, blk_max);  // lower bound of the cell's final masked maximum (0: none yet)
+  const float thr_lb = lb ? (float)((double)float_order_decode(lb) * quality) : -INFINITY;
 #pragma unroll
   for (int k = 0; k < SC_TH * SC_TW / 256; k++) {
-    const int i = threadIdx.x + 256 * k;
-    const int y = i / SC_TW, x = i - y * SC_TW;
+    const int x = threadIdx.x & (SC_TW - 1), y = (threadIdx.x >> 6) + 4 * k;  // position in the lambda block
     const int cx = cx0 + x, cy = cy0 + y;
-    mk[k] = 1u;
-    if (M && cx < cw && cy < ch) mk[k] = M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)];
-  }
-  for (int i = threadIdx.x; i < LH * LW; i += 256) {
-    const int y = i / LW, x = i - y * LW;
-    const int cx = cx0 - 1 + x, cy = cy0 - 1 + y;
-    float v = 0.f;  // outside the cell: never read by an interior pixel's 3x3 test
-    if (cx >= 0 && cx < cw && cy >= 0 && cy < ch) {
-      v = L[cy * cw + cx];
-      v = v > thr ? v : 0.f;  // cv::threshold(THRESH_TOZERO)
-    }
-    s_lam[i] = v;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < SC_TH * SC_TW / 256; k++) {
-    const int i = threadIdx.x + 256 * k;
-    const int y = i / SC_TW, x = i - y * SC_TW;
-    const int cx = cx0 + x, cy = cy0 + y;
-    if (cx >= 1 && cx < cw - 1 && cy >= 1 && cy < ch - 1) {
-      const float* c = s_lam + (y + 1) * LW + (x + 1);
+    if (x >= 1 && x <= SC_TW - 2 && y >= 1 && y <= SC_TH - 2 && cx >= 1 && cx < cw - 1 && cy >= 1 && cy < ch - 1) {
+      const float* c = s_lam + y * SC_LP + x;
       const float v = c[0];
-      if (v != 0.f) {
+      if (v > 0.f && v > thr_lb && s_msk[y * SC_TW + x]) {
         float m = v;
 #pragma unroll
         for (int j = -1; j <= 1; j++)
 #pragma unroll
-          for (int q = -1; q <= 1; q++) m = fmaxf(m, c[j * LW + q]);
-        if (v == m && mk[k]) {
+          for (int q = -1; q <= 1; q++) m = fmaxf(m, c[j * SC_LP + q]);
+        if (v == m) {
+          // key = lambda bits << 32 | raster index: unsigned order = cv's greaterThanPtr order (value, then address)
           const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)(cy * cw + cx);
           const int ls = atomicAdd(&s_n, 1);
-          if (ls < LCAP) {
+          if (ls < SC_LCAP) {
             s_keys[ls] = key;
           } else {
-            const int slot = atomicAdd(&cand_cnt[stream * G.ncell + cell], 1);
-            if (slot < cand_cap) cand[((long long)stream * G.ncell + cell) * cand_cap + slot] = key;
+            const int slot = atomicAdd(ccnt, 1);
+            if (slot < cand_cap) cand[slot] = key;
           }
         }
       }
     }
   }
   __syncthreads();
-  const int nl = min(s_n, LCAP);
-  if (threadIdx.x == 0 && nl > 0) s_base = atomicAdd(&cand_cnt[stream * G.ncell + cell], nl);
+  // ONE global atomic per block reserves the slots of its keys in the cell's list (order does not matter)
+  const int nl = min(s_n, SC_LCAP);
+  if (threadIdx.x == 0 && nl > 0) s_base = atomicAdd(ccnt, nl);
   __syncthreads();
   for (int i = threadIdx.x; i < nl; i += 256) {
     const int slot = s_base + i;
-    if (slot < cand_cap) cand[((long long)stream * G.ncell + cell) * cand_cap + slot] = s_keys[i];
+    if (slot < cand_cap) cand[slot] = s_keys[i];
+  }
+}
+
+// Fused score + candidates.  Grid: (tiles * cells, streams), or with stream_major (streams, tiles * cells): the ANMS
+// detector's single whole-frame cell, where the blocks in flight should belong to many streams -- every block ends
+// with one returning atomic on its cell's counter, and with the tiles of ONE cell in flight together a few hundred
+// blocks queue on one address (the L2's same-address atomic rate: 1.67 against 1.30 ms per 1024 frames, measured on
+// the former separate candidates kernel).
+template <int BS>
+__global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
+                                                    int row_stride, int w, int h,
+                                                    const uint8_t* __restrict__ masks, long long mask_sstride,
+                                                    int mask_row_stride, GridView G,
+                                                    const int* __restrict__ n_active, int tiles_x, int tiles_y,
+                                                    float k_side, float k_mid, double quality,
+                                                    unsigned int* __restrict__ cell_max,
+                                                    unsigned long long* __restrict__ cand, int cand_cap,
+                                                    int* __restrict__ cand_cnt, int stream_major) {
+  const int stream = stream_major ? blockIdx.x : blockIdx.y;
+  const int tc = stream_major ? blockIdx.y : blockIdx.x;
+  const int tpc = tiles_x * tiles_y;
+  const int cell = tc / tpc, tile = tc - cell * tpc;
+  if (cell >= n_active[stream]) return;
+  const int sc = stream * G.ncell + cell;
+  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+  score_tile<BS, false, true>(frames + (long long)stream * frame_sstride, row_stride, w, h,
+                              masks ? masks + (long long)stream * mask_sstride : nullptr, mask_row_stride,
+                              G.rects[cell], tx, ty, k_side, k_mid, nullptr, cell_max + sc, quality,
+                              cand + (long long)sc * cand_cap, cand_cap, cand_cnt + sc);
+}
+
+// The lambda map of the cells whose candidate list overflowed (select_kernel / anms_topk_kernel then re-derive the
+// candidates from the map: exact, slow), or of ONE cell regardless (force_cell >= 0: vsf_debug_min_eig).  Same tile
+// routine, so the same arithmetic.  Grid: (cells, streams); a block walks the tiles of its cell.
+template <int BS>
+__global__ __launch_bounds__(256) void lam_fill_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
+                                                       int row_stride, int w, int h,
+                                                       const uint8_t* __restrict__ masks, long long mask_sstride,
+                                                       int mask_row_stride, GridView G,
+                                                       const int* __restrict__ n_active, int tiles_x, int tiles_y,
+                                                       float k_side, float k_mid, float* __restrict__ lam,
+                                                       unsigned int* __restrict__ cell_max,
+                                                       const int* __restrict__ cand_cnt, int cand_cap, int force_cell) {
+  const int stream = blockIdx.y, cell = blockIdx.x;
+  const int sc = stream * G.ncell + cell;
+  if (force_cell >= 0) {
+    if (cell != force_cell) return;
+  } else if (cell >= n_active[stream] || cand_cnt[sc] <= cand_cap) {
+    return;
+  }
+  float* lam_cell = lam + (long long)stream * G.lam_total + G.lam_off[cell];
+  for (int t = 0; t < tiles_x * tiles_y; t++) {
+    const int ty = t / tiles_x, tx = t - ty * tiles_x;
+    score_tile<BS, true, false>(frames + (long long)stream * frame_sstride, row_stride, w, h,
+                                masks ? masks + (long long)stream * mask_sstride : nullptr, mask_row_stride,
+                                G.rects[cell], tx, ty, k_side, k_mid, lam_cell, cell_max + sc, 0.0, nullptr, 0, nullptr);
+    __syncthreads();  // the tile's LDS is reused by the next one
   }
 }
 
@@ -1579,7 +1643,6 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
   const int want = min(need[sc], sp.sel_cap);
   const int total = cand_cnt[sc];
   const bool overflow = total > sp.cand_cap;
-  const int M = overflow ? cw * ch : total;
   const float* L = lam + (long long)stream * G.lam_total + G.lam_off[cell];
   const uint8_t* Mk = masks ? masks + (long long)stream * mask_sstride : nullptr;
   const unsigned int enc = cell_max[sc];
@@ -1588,9 +1651,18 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
   const bool use_dist = sp.min_dist >= 1.0;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
-  if (!overflow)
-    for (int i = threadIdx.x; i < M; i += 256) s_key[i] = cand[(long long)sc * sp.cand_cap + i];
+  // the list holds every positive local maximum the score kernel could not rule out; cv's threshold
+  // (lambda > (float)(max * quality)) is applied here, and the survivors are compacted in LDS
+  __shared__ int s_m;
+  if (threadIdx.x == 0) s_m = 0;
   __syncthreads();
+  if (!overflow)
+    for (int i = threadIdx.x; i < total; i += 256) {
+      const unsigned long long k = cand[(long long)sc * sp.cand_cap + i];
+      if (__uint_as_float((unsigned int)(k >> 32)) > thr) s_key[atomicAdd(&s_m, 1)] = k;
+    }
+  __syncthreads();
+  const int M = overflow ? cw * ch : s_m;
 
   int accepted = 0;
   int lastx = -1000000, lasty = -1000000;
