@@ -1,0 +1,1028 @@
+// vsf_lk.hpp -- pyramidal Lucas-Kanade (cv::calcOpticalFlowPyrLK) on gfx950.
+// Included by vsf_kernels.hpp after the common declarations (PyrView, LkParams, reflect101).
+#pragma once
+
+namespace vsf {
+
+// ------------------------------------------------------------------------------------------------
+// Pyramidal LK (cv::calcOpticalFlowPyrLK scalar semantics), one wavefront per
+// feature.  Lane l owns window row r = l / nseg and the seglen consecutive pixels starting at
+// (l % nseg) * seglen, so the template (I, Ix, Iy as int16 values) lives in registers for the whole
+// level and only the J patch is re-read per iteration, from an LDS-staged region.  The Scharr
+// derivative is fused: the wave stages the (win+3)^2 patch of I in LDS and derives the (win+1)^2
+// gradient patch there; no derivative image is ever written to HBM.
+// Sums of products are accumulated exactly (int32 per lane, int64 across the wave) and converted
+// to float32 once: order independent, equal to the oracle's ORC_ACC_EXACT mode bit for bit.
+// ------------------------------------------------------------------------------------------------
+// ---- exact wave-wide integer sums -------------------------------------------------------------
+// Every lane ends up holding the sum of its 16-lane row; DPP adds, no LDS traffic.
+__device__ __forceinline__ int row_sum_dpp(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+  v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+  v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+  return v;
+}
+// Wave-uniform (scalar) sum of a per-lane int32; the caller guarantees no overflow.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v = row_sum_dpp(v);
+  return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) +
+         __builtin_amdgcn_readlane(v, 48);
+}
+// float32(sum over the wave of p), correctly rounded from the EXACT integer sum: the per-lane value
+// is split into a 16-bit low limb and a signed high limb so that both 64-lane sums fit int32; the
+// recombination in double is exact (< 2^53) and rounds to float32 once.
+__device__ __forceinline__ float wave_sum_exact_f32(int p) {
+  const int slo = wave_sum_i32(p & 0xffff);
+  const int shi = wave_sum_i32(p >> 16);
+  return (float)((double)shi * 65536.0 + (double)slo);
+}
+// The same for N values at once.  Each |p| must be < 2^29 (true for every sum here: <= 16 pixels x
+// 8160 x 4080), so the first two DPP steps (sums over quads) still fit int32; only then is each value
+// split into the two limbs, which halves the DPP adds of those steps.  The limb chains are
+// interleaved so that no chain waits on its own previous step.  The recombination takes the int32
+// route (one v_cvt_f32_i32, exact round-to-nearest-even) whenever the total fits 32 bits and the
+// double route otherwise; both round the EXACT integer sum once.
+template <int N>
+__device__ __forceinline__ void wave_sums_exact_f32(const int (&p)[N], float (&out)[N]) {
+  int q[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = p[i] + __builtin_amdgcn_update_dpp(0, p[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] += __builtin_amdgcn_update_dpp(0, q[i], 0x4E, 0xf, 0xf, false);
+  int v[2 * N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    v[2 * i] = q[i] & 0xffff;
+    v[2 * i + 1] = q[i] >> 16;
+  }
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x141, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < 2 * N; i++) v[i] += __builtin_amdgcn_update_dpp(0, v[i], 0x140, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const int slo = __builtin_amdgcn_readlane(v[2 * i], 0) + __builtin_amdgcn_readlane(v[2 * i], 16) +
+                    __builtin_amdgcn_readlane(v[2 * i], 32) + __builtin_amdgcn_readlane(v[2 * i], 48);
+    const int shi = __builtin_amdgcn_readlane(v[2 * i + 1], 0) + __builtin_amdgcn_readlane(v[2 * i + 1], 16) +
+                    __builtin_amdgcn_readlane(v[2 * i + 1], 32) + __builtin_amdgcn_readlane(v[2 * i + 1], 48);
+    // slo < 2^22 here, so shi in [-32768, 32766] keeps shi*65536 + slo inside int32
+    if (shi >= -32768 && shi <= 32766)
+      out[i] = (float)(shi * 65536 + slo);
+    else
+      out[i] = (float)((double)shi * 65536.0 + (double)slo);
+  }
+}
+
+// v_readfirstlane the compiler cannot look through: the result is an SGPR, and everything computed
+// from it stays on the scalar unit instead of being folded back into vector instructions.
+// gfx940/950 need one wait state between a VALU write of a VGPR and a v_readlane of it, and two
+// between a VALU write of an SGPR and a VALU read of it; the compiler inserts them for its own
+// instructions but cannot see inside an asm statement, so they are part of it (measured: without
+// the leading s_nop the lane read returns the register's previous value).
+__device__ __forceinline__ int to_sgpr(int v) {
+  int s;
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(s) : "v"(v));
+  return s;
+}
+__device__ __forceinline__ int to_sgpr(float v) {
+  int s;
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(s) : "v"(v));
+  return s;
+}
+
+// Several lane reads behind ONE pair of wait states (the leading one covers the first read, the later reads
+// are further away from their producers; the trailing two cover the last SGPR written).
+__device__ __forceinline__ void to_sgpr3(float a, float b, float c, int& sa, int& sb, int& sc) {
+  asm volatile(
+      "s_nop 0\n\tv_readfirstlane_b32 %0, %3\n\tv_readfirstlane_b32 %1, %4\n\tv_readfirstlane_b32 %2, %5\n\ts_nop 1"
+      : "=&s"(sa), "=&s"(sb), "=&s"(sc)
+      : "v"(a), "v"(b), "v"(c));
+}
+__device__ __forceinline__ void to_sgpr2(int a, int b, int& sa, int& sb) {
+  asm volatile("s_nop 0\n\tv_readfirstlane_b32 %0, %2\n\tv_readfirstlane_b32 %1, %3\n\ts_nop 1"
+               : "=&s"(sa), "=&s"(sb)
+               : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void to_sgpr4(int a, int b, int c, int d, int& sa, int& sb, int& sc, int& sd) {
+  asm volatile(
+      "s_nop 0\n\tv_readfirstlane_b32 %0, %4\n\tv_readfirstlane_b32 %1, %5\n\tv_readfirstlane_b32 %2, %6\n\t"
+      "v_readfirstlane_b32 %3, %7\n\ts_nop 1"
+      : "=&s"(sa), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+      : "v"(a), "v"(b), "v"(c), "v"(d));
+}
+
+// The same sums through the LDS ATOMIC unit.  The kernel is VALU-issue bound while the LDS pipe idles, so
+// only the first NRAW butterfly steps run as DPP adds (the values still fit int32: NRAW = 3 needs
+// |p| < 2^28, NRAW = 2 needs |p| < 2^29); then one lane of every 2^NRAW adds its partial sum as a
+// 64-bit integer into an LDS accumulator (lane 0 stores, the others ds_add_u64: LDS operations of one
+// wave execute in issue order), and every lane reads the exact total back.  The total is converted
+// to float32 with ONE rounding: v_cvt_f32_i32 when it fits 32 bits, through double otherwise.
+// Accumulate half: DPP steps, then lane 0 stores and one lane of every 2^NRAW adds (ds_add_u64) into acc[0..N).
+// Nothing is read back here; the reader (this wave or, in the four-wave kernel, the solver wave after a
+// workgroup barrier) finds the exact 64-bit totals in acc.
+template <int N, int NRAW>
+__device__ __forceinline__ void wave_sums_to_lds(const int (&p)[N], long long* acc, int lane) {
+  int q[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] = p[i] + __builtin_amdgcn_update_dpp(0, p[i], 0xB1, 0xf, 0xf, false);
+#pragma unroll
+  for (int i = 0; i < N; i++) q[i] += __builtin_amdgcn_update_dpp(0, q[i], 0x4E, 0xf, 0xf, false);
+  if constexpr (NRAW == 3) {
+#pragma unroll
+    for (int i = 0; i < N; i++) q[i] += __builtin_amdgcn_update_dpp(0, q[i], 0x141, 0xf, 0xf, false);
+  }
+  constexpr int LM = (1 << NRAW) - 1;
+  // LDS byte address of the accumulators.  The steps are written as inline asm: left to the compiler, the
+  // atomic is "optimised" into a serial v_readlane loop over the active lanes, which is exactly the VALU
+  // work this routine exists to avoid.
+  const unsigned int a32 = (unsigned int)(size_t)(__attribute__((address_space(3))) void*)acc;
+  static_assert(N == 2 || N == 3, "two or three sums");
+  long long q64[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) q64[i] = (long long)q[i];
+  if (lane == 0) {
+    if constexpr (N == 2)
+      asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" ::"v"(a32), "v"(q64[0]), "v"(q64[1])
+                   : "memory");
+    else
+      asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8\n\tds_write_b64 %0, %3 offset:16" ::"v"(a32),
+                   "v"(q64[0]), "v"(q64[1]), "v"(q64[N - 1])
+                   : "memory");
+  }
+  // convergent barriers keep the store, the adds and the loads in this order in the instruction
+  // stream (per lane they are mutually exclusive, so nothing else orders them for the compiler)
+  __builtin_amdgcn_wave_barrier();
+  if (lane != 0 && (lane & LM) == 0) {
+    if constexpr (N == 2)
+      asm volatile("ds_add_u64 %0, %1\n\tds_add_u64 %0, %2 offset:8" ::"v"(a32), "v"(q64[0]), "v"(q64[1]) : "memory");
+    else
+      asm volatile("ds_add_u64 %0, %1\n\tds_add_u64 %0, %2 offset:8\n\tds_add_u64 %0, %3 offset:16" ::"v"(a32),
+                   "v"(q64[0]), "v"(q64[1]), "v"(q64[N - 1])
+                   : "memory");
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
+// float32 of an exact 64-bit integer total, ONE rounding: v_cvt_f32_i32 when it fits 32 bits, through double otherwise
+__device__ __forceinline__ float exact_i64_to_f32(int lo, int hi) {
+  if (hi == (lo >> 31)) return (float)lo;
+  return (float)((double)hi * 4294967296.0 + (double)(unsigned int)lo);
+}
+
+template <int N, int NRAW>
+__device__ __forceinline__ void wave_sums_exact_lds(const int (&p)[N], float (&out)[N], long long* acc, int lane) {
+  wave_sums_to_lds<N, NRAW>(p, acc, lane);
+  const unsigned int a32 = (unsigned int)(size_t)(__attribute__((address_space(3))) void*)acc;
+  long long t[N];
+  if constexpr (N == 2) {
+    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(t[0]), "=&v"(t[1])
+                 : "v"(a32)
+                 : "memory");
+  } else {
+    asm volatile(
+        "ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[N - 1])
+        : "v"(a32)
+        : "memory");
+  }
+  int los[N], his[N];
+  if constexpr (N == 2) {
+    to_sgpr4((int)(unsigned int)(unsigned long long)t[0], (int)(t[0] >> 32), (int)(unsigned int)(unsigned long long)t[1],
+             (int)(t[1] >> 32), los[0], his[0], los[1], his[1]);
+  } else {
+    to_sgpr4((int)(unsigned int)(unsigned long long)t[0], (int)(t[0] >> 32), (int)(unsigned int)(unsigned long long)t[1],
+             (int)(t[1] >> 32), los[0], his[0], los[1], his[1]);
+    to_sgpr2((int)(unsigned int)(unsigned long long)t[N - 1], (int)(t[N - 1] >> 32), los[N - 1], his[N - 1]);
+  }
+  // scalar from here on: the range test and the recombination cost no vector instruction
+#pragma unroll
+  for (int i = 0; i < N; i++) out[i] = exact_i64_to_f32(los[i], his[i]);
+}
+
+// The four weights of a wave-uniform sub-pixel offset, as scalars.  cvRound(x * 2^14), x in [0, 1]:
+// scaling by 2^14 is exact, so it is applied to one factor before the product; adding 1.5 * 2^23
+// rounds the product to an integer with ties to even (the parity of the sum is the parity of the
+// integer part), which is what cvRound / rint do; the integer is then the low mantissa bits.
+__device__ __forceinline__ void bilinear_weights_uniform(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+  const float MAGIC = 12582912.f;  // 1.5 * 2^23
+  const float a1 = 1.f - a;
+  const float b1 = (1.f - b) * (float)(1 << W_BITS), b0 = b * (float)(1 << W_BITS);
+  int s00, s01, s10;
+  to_sgpr3(a1 * b1 + MAGIC, a * b1 + MAGIC, a1 * b0 + MAGIC, s00, s01, s10);
+  w00 = s00 - 0x4B400000;
+  w01 = s01 - 0x4B400000;
+  w10 = s10 - 0x4B400000;
+  w11 = (1 << W_BITS) - w00 - w01 - w10;
+}
+
+__device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
+  w00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+  w01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
+  w10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
+  w11 = (1 << W_BITS) - w00 - w01 - w10;
+}
+
+#define VSF_DESCALE(x, n) (((x) + (1 << ((n)-1))) >> (n))
+
+typedef short vsf_i16x2 __attribute__((ext_vector_type(2)));
+
+// a.lo*b.lo + a.hi*b.hi + c on packed SIGNED 16-bit pairs (v_dot2_i32_i16).  Signed because the
+// fourth bilinear weight, 2^14 - w00 - w01 - w10, can come out as -1 after rounding.
+__device__ __forceinline__ int sdot2(unsigned int a, unsigned int b, int c) {
+  return __builtin_amdgcn_sdot2(__builtin_bit_cast(vsf_i16x2, a), __builtin_bit_cast(vsf_i16x2, b), c, false);
+}
+
+// (lo & 0xffff) | (hi << 16) in one v_perm_b32
+__device__ __forceinline__ unsigned int pack_lo16(int lo, int hi) {
+  return __builtin_amdgcn_perm((unsigned int)hi, (unsigned int)lo, 0x05040100u);
+}
+
+// Reads NA+... dwords of an LDS byte row starting at byte offset `boff` and returns, in A[], the byte
+// stream re-aligned so that A[0] byte 0 is the byte at `boff`.
+template <int NA>
+__device__ __forceinline__ void lds_stream(const uint8_t* row, int boff, unsigned int (&A)[NA]) {
+  const unsigned int* w = reinterpret_cast<const unsigned int*>(row) + (boff >> 2);
+  const unsigned int o = (unsigned int)boff & 3u;
+  unsigned int d[NA + 1];
+#pragma unroll
+  for (int i = 0; i < NA + 1; i++) d[i] = w[i];
+#pragma unroll
+  for (int i = 0; i < NA; i++) A[i] = __builtin_amdgcn_alignbyte(d[i + 1], d[i], o);
+}
+
+// Two consecutive LDS rows (pitch a multiple of 4, rows dword aligned) read from the byte address p
+// of the first one: one address split serves both rows.
+template <int NA>
+__device__ __forceinline__ void lds_stream_at(const uint8_t* p, int pitch, unsigned int (&A0)[NA],
+                                              unsigned int (&A1)[NA]) {
+  const unsigned int o = (unsigned int)reinterpret_cast<uintptr_t>(p) & 3u;
+  const unsigned int* w0 = reinterpret_cast<const unsigned int*>(p - o);
+  const unsigned int* w1 = reinterpret_cast<const unsigned int*>(p - o + pitch);
+  unsigned int d0[NA + 1], d1[NA + 1];
+#pragma unroll
+  for (int i = 0; i < NA + 1; i++) d0[i] = w0[i];
+#pragma unroll
+  for (int i = 0; i < NA + 1; i++) d1[i] = w1[i];
+#pragma unroll
+  for (int i = 0; i < NA; i++) A0[i] = __builtin_amdgcn_alignbyte(d0[i + 1], d0[i], o);
+#pragma unroll
+  for (int i = 0; i < NA; i++) A1[i] = __builtin_amdgcn_alignbyte(d1[i + 1], d1[i], o);
+}
+
+// (byte k) | (byte k+1) << 16 of a dword stream (v_perm_b32; selector 0x0c = zero byte)
+template <int K, int NA>
+__device__ __forceinline__ unsigned int byte_pair(const unsigned int (&A)[NA]) {
+  constexpr int j = K >> 2, m = K & 3;
+  if constexpr (m < 3) {
+    return __builtin_amdgcn_perm(0u, A[j], 0x0c000c00u | (unsigned int)m | ((unsigned int)(m + 1) << 16));
+  } else {
+    return __builtin_amdgcn_perm(A[j + 1], A[j], 0x0c040c03u);
+  }
+}
+
+template <int K, int N, int NA, int C0>
+struct BilinearRow {
+  // out[k] = C0 + sum over the 2x2 neighbourhood, for k = K..N-1 (compile-time recursion keeps every
+  // index a constant, so the arrays stay in registers).  C0 carries DESCALE's rounding constant.
+  static __device__ __forceinline__ void run(const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
+                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
+    out[K] = sdot2(byte_pair<K, NA>(A1), W1, sdot2(byte_pair<K, NA>(A0), W0, C0));
+    if constexpr (K + 1 < N) BilinearRow<K + 1, N, NA, C0>::run(A0, A1, W0, W1, out);
+  }
+};
+
+typedef unsigned short vsf_u16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int udot2(unsigned int a, unsigned int b, int c) {
+  return (int)__builtin_amdgcn_udot2(__builtin_bit_cast(vsf_u16x2, a), __builtin_bit_cast(vsf_u16x2, b),
+                                     (unsigned int)c, false);
+}
+
+// Unsigned twin of BilinearRow for the common case of four non-negative weights: v_dot2_u32_u16 is a
+// three-operand instruction, so the accumulator constant needs no v_mov per pixel (the signed form
+// on gfx950 is the two-operand v_dot2c_i32_i16).
+template <int K, int N, int NA, int C0>
+struct BilinearRowU {
+  static __device__ __forceinline__ void run(const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
+                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
+    out[K] = udot2(byte_pair<K, NA>(A1), W1, udot2(byte_pair<K, NA>(A0), W0, C0));
+    if constexpr (K + 1 < N) BilinearRowU<K + 1, N, NA, C0>::run(A0, A1, W0, W1, out);
+  }
+};
+
+template <int N, int NA, int C0>
+__device__ __forceinline__ void bilinear_row(bool nonneg, const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
+                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
+  if (nonneg)
+    BilinearRowU<0, N, NA, C0>::run(A0, A1, W0, W1, out);
+  else
+    BilinearRow<0, N, NA, C0>::run(A0, A1, W0, W1, out);
+}
+
+// LDS carve-up per wave and the geometry of the two staged regions
+struct RegionGeom {
+  int ndw;    // staged dwords per row
+  int inv;    // ceil(2^16 / ndw): (t * inv) >> 16 == t / ndw for every task index used
+  int rows;   // staged rows
+  int pitch;  // LDS bytes per row: 4 * (ndw | 1), odd in dwords so that window rows hit distinct banks
+};
+
+struct LkSmem {
+  RegionGeom gi;  // template patch of I: (win+3) rows, covers win+3 columns at any 4-byte phase
+  RegionGeom gj;  // J region: window + margin
+  int d_pitch;    // gradient patch (win+1)^2, packed (Ix | Iy<<16) int32 (generic path only)
+  int jp_pitch;   // J region in PAIR layout: dwords per row (4 * gj.ndw pairs + 2 of padding)
+  int off_j, off_d;
+  int off_acc;   // 4 x int64 accumulators of the exact sums
+  int off_mask;  // per lane: NP dwords, 16-bit masks of the window pixels the lane owns (pair-packed)
+  int total;
+};
+
+// Pixels per lane: the window row is cut into nseg = 64 / win segments of seglen pixels.
+__host__ __device__ inline int lk_seglen(int win) {
+  const int nseg = 64 / win;
+  return (win + nseg - 1) / nseg;
+}
+// Kernel instantiation (compile-time pixels per lane) that serves a given seglen.
+__host__ __device__ inline int lk_seg_template(int seglen) { return seglen <= 7 ? 7 : (seglen <= 8 ? 8 : 16); }
+
+__host__ __device__ inline RegionGeom vsf_region_geom(int cols_needed, int rows) {
+  RegionGeom g;
+  g.ndw = (cols_needed + 3 + 3) / 4;  // any 4-byte phase of the origin
+  g.inv = (65536 + g.ndw - 1) / g.ndw;
+  g.rows = rows;
+  g.pitch = 4 * (g.ndw | 1);
+  return g;
+}
+
+__host__ __device__ inline LkSmem lk_smem_layout(int win, int jmargin) {
+  LkSmem s;
+  s.gi = vsf_region_geom(win + 3, win + 3);
+  s.gj = vsf_region_geom(win + 1 + 2 * jmargin, win + 1 + 2 * jmargin);
+  s.d_pitch = win + 1;
+  const int si = s.gi.pitch * s.gi.rows + 32;  // +slack: dword-granular readers may run past a row end
+  s.off_j = (si + 15) & ~15;
+  // The J region is kept as pixel PAIRS, one dword per pixel: byte(x) | byte(x + 1) << 16, the operand v_dot2
+  // takes, so the iterations spend no v_perm / v_alignbyte on it.  The gradient patch of the border path (sD)
+  // is dead before the first J staging of a level and shares the space.
+  s.jp_pitch = 4 * s.gj.ndw + 2;
+  const int sj = s.jp_pitch * 4 * s.gj.rows + 64, sd = s.d_pitch * (win + 1) * 4;
+  s.off_d = s.off_j;
+  s.off_acc = s.off_j + (((sj > sd ? sj : sd) + 15) & ~15);
+  s.off_mask = s.off_acc + 32;
+  const int np = (lk_seg_template(lk_seglen(win)) + 1) / 2;
+  s.total = s.off_mask + 64 * 4 * np;
+#ifdef VSF_LDS_PAD  // occupancy experiments
+  s.total += VSF_LDS_PAD;
+#endif
+  return s;
+}
+
+// A region [xa, xa + 4*ndw) x [y0, y0 + rows) can be fetched as aligned dwords when it lies inside
+// the level and rows are dword aligned; otherwise it is assembled byte by byte with REFLECT_101.
+__device__ __forceinline__ bool region_is_fast(const uint8_t* src, int sp, int sw, int sh, int xa, int y0,
+                                               const RegionGeom& g) {
+  return xa >= 0 && y0 >= 0 && xa + 4 * g.ndw <= sw && y0 + g.rows <= sh && (sp & 3) == 0 &&
+         ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+}
+
+// Staging map (no division): lane -> dword column xd = lane % C and row yl = lane / C, with C = 8 when
+// the region is at most 8 dwords wide and 16 otherwise; task i covers row yl + i * (64 / C).
+// Issues the aligned dword loads of a fast region into registers (no wait).  The source pointer is
+// wave-uniform, so each load is a scalar base plus a 32-bit lane offset.
+template <int N>
+__device__ __forceinline__ void region_load_regs(unsigned int (&reg)[N], const uint8_t* __restrict__ src, int sp,
+                                                 int xa, int y0, const RegionGeom& g, int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  const unsigned int* s = reinterpret_cast<const unsigned int*>(src + (long long)y0 * sp + xa);
+  const unsigned int spw = (unsigned int)sp >> 2;
+  const unsigned int off = (unsigned int)yl * spw + (unsigned int)xd, step = (unsigned int)ystep * spw;
+  const bool xin = xd < g.ndw;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    reg[i] = 0u;
+    if (xin && yl + i * ystep < g.rows) reg[i] = s[off + (unsigned int)i * step];
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void region_store_regs(uint8_t* dst, const unsigned int (&reg)[N], const RegionGeom& g,
+                                                  int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  unsigned int* d = reinterpret_cast<unsigned int*>(dst);
+  const int pw = g.pitch >> 2;
+  const int off = yl * pw + xd, step = ystep * pw;
+  const bool xin = xd < g.ndw;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    if (xin && yl + i * ystep < g.rows) d[off + i * step] = reg[i];
+  }
+}
+
+// Border path: values identical to OpenCV's reflect-padded pyramid level.
+template <int N>
+__device__ __forceinline__ void region_stage_slow(uint8_t* dst, const uint8_t* __restrict__ src, int sp, int sw,
+                                                  int sh, int xa, int y0, const RegionGeom& g, int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  unsigned int* d = reinterpret_cast<unsigned int*>(dst);
+  const int pw = g.pitch >> 2;
+  if (xd < g.ndw) {
+    for (int y = yl; y < g.rows; y += ystep) {
+      const uint8_t* sr = src + (long long)reflect101(y0 + y, sh) * sp;
+      unsigned int v = 0u;
+#pragma unroll
+      for (int b = 0; b < 4; b++) v |= (unsigned int)sr[reflect101(xa + 4 * xd + b, sw)] << (8 * b);
+      d[y * pw + xd] = v;
+    }
+  }
+}
+
+// ---- pair layout (J region): LDS dword (row, x) = byte(x) | byte(x + 1) << 16
+__device__ __forceinline__ void pairs_of_dword(unsigned int d0, unsigned int d1, unsigned int (&P)[4]) {
+  P[0] = __builtin_amdgcn_perm(0u, d0, 0x0c010c00u);
+  P[1] = __builtin_amdgcn_perm(0u, d0, 0x0c020c01u);
+  P[2] = __builtin_amdgcn_perm(0u, d0, 0x0c030c02u);
+  P[3] = __builtin_amdgcn_perm(d1, d0, 0x0c040c03u);
+}
+
+// Registers of region_load_regs -> pair layout.  The dword to the right is the next lane's (the staging map puts
+// consecutive columns on consecutive lanes of a 16-lane DPP row); the last column's fourth pair would need a
+// byte outside the region and is never read (the iterations restage before the window reaches it).
+template <int N>
+__device__ __forceinline__ void region_store_pairs(unsigned int* dst, const unsigned int (&reg)[N], const RegionGeom& g,
+                                                   int pitch_dw, int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  const int off = yl * pitch_dw + 4 * xd, step = ystep * pitch_dw;
+  const bool xin = xd < g.ndw;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const unsigned int right = (unsigned int)__builtin_amdgcn_update_dpp(0, (int)reg[i], 0x101, 0xf, 0xf, true);  // row_shl:1
+    unsigned int P[4];
+    pairs_of_dword(reg[i], right, P);
+    if (xin && yl + i * ystep < g.rows) {
+      unsigned int* d = dst + off + i * step;
+      d[0] = P[0];
+      d[1] = P[1];
+      d[2] = P[2];
+      d[3] = P[3];
+    }
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void region_stage_slow_pairs(unsigned int* dst, const uint8_t* __restrict__ src, int sp,
+                                                        int sw, int sh, int xa, int y0, const RegionGeom& g,
+                                                        int pitch_dw, int lane) {
+  const int cl = g.ndw <= 8 ? 3 : 4;
+  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  if (xd < g.ndw) {
+    for (int y = yl; y < g.rows; y += ystep) {
+      const uint8_t* sr = src + (long long)reflect101(y0 + y, sh) * sp;
+      unsigned int b[5];
+#pragma unroll
+      for (int k = 0; k < 5; k++) b[k] = (unsigned int)sr[reflect101(xa + 4 * xd + k, sw)];
+      unsigned int* d = dst + y * pitch_dw + 4 * xd;
+#pragma unroll
+      for (int k = 0; k < 4; k++) d[k] = b[k] | (b[k + 1] << 16);
+    }
+  }
+}
+
+// One wave's LDS ordering point: LDS operations of a wave execute in issue order, so a store by one lane is seen
+// by a later load of another lane of the SAME wave without any wait; the fence only keeps the compiler from moving
+// memory operations across it.  (The single-wave kernels used __syncthreads() here; the four-wave kernel cannot:
+// its waves reach these points independently.)
+__device__ __forceinline__ void lk_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Per-level lane map: lane l owns window row r = l / nseg and seglen pixels from x0 = (l % nseg) * seglen.
+struct LkLaneMap {
+  int rowI;                  // byte offset of the lane's row in the I patch
+  const unsigned int* rowJ0; // the lane's first pixel in the J pair region (row rr, column xx0)
+  const unsigned int* sMask; // the lane's ownership masks
+  int rr, xx0;
+};
+
+template <int SEG>
+__device__ __forceinline__ LkLaneMap lk_lane_map(int lane, const LkParams& prm, uint8_t* smem, const LkSmem& L) {
+  constexpr int NP = (SEG + 1) / 2;
+  LkLaneMap m;
+  const int r = (lane * prm.nseg_inv) >> 16;  // lane / nseg
+  const int x0 = (lane - r * prm.nseg) * prm.seglen;
+  const bool owner = (r < prm.win) && (x0 < prm.win);  // lane owns at least one window pixel
+  m.rr = owner ? r : 0;                                // idle lanes read a valid (unused) place
+  m.xx0 = owner ? x0 : 0;
+  m.sMask = reinterpret_cast<const unsigned int*>(smem + L.off_mask) + lane * NP;
+  m.rowI = __mul24(m.rr, L.gi.pitch);
+  m.rowJ0 = reinterpret_cast<unsigned int*>(smem + L.off_j) + __mul24(m.rr, L.jp_pitch) + m.xx0;
+  return m;
+}
+
+// This level's I patch into LDS: aligned dwords when interior, assembled byte-wise at the border.
+// ipx, ipy wave-uniform.
+template <int SEG>
+__device__ __forceinline__ void lk_stage_i(const PyrView& A, int level, int stream, int ipx, int ipy, uint8_t* sI,
+                                           const LkSmem& L, int lane) {
+  constexpr int NI = (SEG <= 8) ? 3 : 9;  // I-patch staging tasks per lane (win <= 21: 24 rows / 8; <= 31: 34 / 4)
+  const int aw = A.w[level], ah = A.h[level];
+  const int xaI = (ipx - 1) & ~3;
+  const uint8_t* Ab = A.base[level] + (long long)stream * A.sstride[level];
+  if (region_is_fast(Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi)) {
+    unsigned int ri[NI];
+    region_load_regs<NI>(ri, Ab, A.pitch[level], xaI, ipy - 1, L.gi, lane);
+    region_store_regs<NI>(sI, ri, L.gi, lane);
+  } else {
+    region_stage_slow<NI>(sI, Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi, lane);
+  }
+}
+
+// The template of a level from the staged I patch: interpolated intensities and Scharr gradients of the lane's
+// pixels.  Out: gradients pair-packed (IxP[k2] = Ix[2k2] | Ix[2k2+1] << 16, zero where the lane owns no pixel), the
+// lane's share of sum I*Ix, sum I*Iy (cI1, cI2) and of A11, A12, A22 (part).  All weights wave-uniform.
+template <int SEG>
+__device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, const LkParams& prm, const LkLaneMap& m,
+                                            int lane, int aw, int ah, int ipx, int ipy, bool interior, int iw00,
+                                            int iw01, int iw10, int iw11, unsigned int (&IxP)[(SEG + 1) / 2],
+                                            unsigned int (&IyP)[(SEG + 1) / 2], int& cI1, int& cI2, int (&part)[3]) {
+  constexpr int NA = (SEG + 1 + 3) / 4;  // aligned dwords holding SEG+1 bytes
+  constexpr int NP = (SEG + 1) / 2;      // pixel pairs per lane
+  const int win = prm.win;
+  uint8_t* sI = smem;
+  int* sD = reinterpret_cast<int*>(smem + L.off_d);
+  const int oI = (ipx - 1) - ((ipx - 1) & ~3);
+  const int rowI = m.rowI, rr = m.rr, xx0 = m.xx0;
+  int Iw[SEG + 1];
+  Iw[SEG] = 0;
+  const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
+  const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
+  unsigned int pm[NP];
+#pragma unroll
+  for (int k2 = 0; k2 < NP; k2++) pm[k2] = m.sMask[k2];
+  if (interior) {
+    // Fast path.  The Scharr operator and the bilinear interpolation are both linear and integer,
+    // so sum_w(w * Scharr(I)) == Scharr(V) with V = sum_w(w * I) (22 bits) evaluated on the window
+    // grid plus a one-pixel ring.  Each lane forms V on 3 rows x (SEG+2) columns from 4 patch
+    // rows, then applies the separable Scharr stencil; nothing goes through LDS again.
+    constexpr int NC = SEG + 2;            // V columns: window columns xx0-1 .. xx0+SEG
+    constexpr int NAV = (NC + 1 + 3) / 4;  // aligned dwords holding NC+1 bytes
+    // The three V rows are produced one after the other and folded into the vertical Scharr sums
+    // at once (T0 = 3 V0 + 10 V1 + 3 V2, T1 = V2 - V0), so at most one V row is live.
+    const uint8_t* rI = sI + rowI;
+    const bool wpos = iw11 >= 0;  // the other three weights are rounded products of non-negatives
+    int T0[NC], T1[NC];
+    {
+      unsigned int Ra[NAV], Rb[NAV];
+      int V[NC];
+      lds_stream<NAV>(rI, oI + xx0, Ra);
+      lds_stream<NAV>(rI + L.gi.pitch, oI + xx0, Rb);
+      bilinear_row<NC, NAV, 0>(wpos, Ra, Rb, W0, W1, V);  // V0
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        T0[c] = __mul24(V[c], 3);
+        T1[c] = -V[c];
+      }
+      lds_stream<NAV>(rI + 2 * L.gi.pitch, oI + xx0, Ra);
+      bilinear_row<NC, NAV, 0>(wpos, Rb, Ra, W0, W1, V);  // V1
+#pragma unroll
+      for (int c = 0; c < NC; c++) T0[c] += __mul24(V[c], 10);
+#pragma unroll
+      for (int k = 0; k < SEG; k++) Iw[k] = VSF_DESCALE(V[k + 1], W_BITS - 5);
+      lds_stream<NAV>(rI + 3 * L.gi.pitch, oI + xx0, Rb);
+      bilinear_row<NC, NAV, 0>(wpos, Ra, Rb, W0, W1, V);  // V2
+#pragma unroll
+      for (int c = 0; c < NC; c++) {
+        T0[c] += __mul24(V[c], 3);  // < 2^27
+        T1[c] += V[c];
+      }
+    }
+    int ixv[SEG + 1], iyv[SEG + 1];
+    ixv[SEG] = 0;
+    iyv[SEG] = 0;
+#pragma unroll
+    for (int k = 0; k < SEG; k++) {
+      ixv[k] = VSF_DESCALE(T0[k + 2] - T0[k], W_BITS);
+      iyv[k] = VSF_DESCALE(3 * (T1[k] + T1[k + 2]) + 10 * T1[k + 1], W_BITS);
+    }
+    // pixels a lane does not own carry zero gradients, so they add nothing to any sum
+#pragma unroll
+    for (int k2 = 0; k2 < NP; k2++) {
+      IxP[k2] = pack_lo16(ixv[2 * k2], ixv[2 * k2 + 1]) & pm[k2];
+      IyP[k2] = pack_lo16(iyv[2 * k2], iyv[2 * k2 + 1]) & pm[k2];
+    }
+  } else {
+    // Generic path (window touches the level border): Scharr gradient patch (win+1)^2 in LDS,
+    // zero outside the level image (BORDER_CONSTANT), then the bilinear template per lane.
+    {
+      const int side = win + 1;
+      const int xs = lane & 31;
+      if (xs < side) {
+        const int gx = ipx + xs;
+        const bool xin = gx >= 0 && gx < aw;
+        for (int y = lane >> 5; y < side; y += 2) {
+          const int gy = ipy + y;
+          int packed = 0;
+          if (xin && gy >= 0 && gy < ah) {
+            const uint8_t* c = sI + (y + 1) * L.gi.pitch + (oI + xs + 1);
+            const int p = L.gi.pitch;
+            const int i00 = c[-p - 1], i01 = c[-p], i02 = c[-p + 1];
+            const int i10 = c[-1], i12 = c[1];
+            const int i20 = c[p - 1], i21 = c[p], i22 = c[p + 1];
+            const int ix = 3 * (i02 - i00) + 10 * (i12 - i10) + 3 * (i22 - i20);
+            const int iy = 3 * (i20 - i00) + 10 * (i21 - i01) + 3 * (i22 - i02);
+            packed = (ix & 0xffff) | (iy << 16);
+          }
+          sD[y * L.d_pitch + xs] = packed;
+        }
+      }
+    }
+    lk_wave_sync();
+    unsigned int R0[NA], R1[NA];
+    lds_stream<NA>(sI + rowI + L.gi.pitch, oI + 1 + xx0, R0);
+    lds_stream<NA>(sI + rowI + 2 * L.gi.pitch, oI + 1 + xx0, R1);
+    int Iv[SEG];
+    BilinearRow<0, SEG, NA, (1 << (W_BITS - 5 - 1))>::run(R0, R1, W0, W1, Iv);
+    const int* d0 = sD + rr * L.d_pitch + xx0;
+    const int* d1 = d0 + L.d_pitch;
+    int ixv[SEG + 1], iyv[SEG + 1];
+    ixv[SEG] = 0;
+    iyv[SEG] = 0;
+#pragma unroll
+    for (int k = 0; k < SEG; k++) {
+      Iw[k] = Iv[k] >> (W_BITS - 5);
+      ixv[k] = 0;
+      iyv[k] = 0;
+      if (k < prm.seglen) {  // d0[k + 1] stays inside the (win+1)-wide patch for every pixel read
+        const int p00 = d0[k], p01 = d0[k + 1], p10 = d1[k], p11 = d1[k + 1];
+        ixv[k] = VSF_DESCALE(__mul24((int)(short)(p00 & 0xffff), iw00) + __mul24((int)(short)(p01 & 0xffff), iw01) +
+                                 __mul24((int)(short)(p10 & 0xffff), iw10) +
+                                 __mul24((int)(short)(p11 & 0xffff), iw11),
+                             W_BITS);
+        iyv[k] = VSF_DESCALE(__mul24(p00 >> 16, iw00) + __mul24(p01 >> 16, iw01) + __mul24(p10 >> 16, iw10) +
+                                 __mul24(p11 >> 16, iw11),
+                             W_BITS);
+      }
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < NP; k2++) {
+      IxP[k2] = pack_lo16(ixv[2 * k2], ixv[2 * k2 + 1]) & pm[k2];
+      IyP[k2] = pack_lo16(iyv[2 * k2], iyv[2 * k2 + 1]) & pm[k2];
+    }
+    lk_wave_sync();  // the gradient patch shares its space with the J region: reads done before any staging
+  }
+  // b = sum (Jw - Iw) * (Ix, Iy) = sum Jw * (Ix, Iy) - (cI1, cI2): the template's own part is a
+  // per-lane constant of the level, so the iterations neither subtract per pixel nor keep Iw live
+  int a11 = 0, a12 = 0, a22 = 0;
+  cI1 = 0;
+  cI2 = 0;
+#pragma unroll
+  for (int k2 = 0; k2 < NP; k2++) {
+    const unsigned int iwp = pack_lo16(Iw[2 * k2], Iw[2 * k2 + 1]);  // 0 <= Iw <= 8160
+    a11 = sdot2(IxP[k2], IxP[k2], a11);
+    a12 = sdot2(IxP[k2], IyP[k2], a12);
+    a22 = sdot2(IyP[k2], IyP[k2], a22);
+    cI1 = sdot2(iwp, IxP[k2], cI1);
+    cI2 = sdot2(iwp, IyP[k2], cI2);
+  }
+  part[0] = a11;
+  part[1] = a12;
+  part[2] = a22;
+}
+
+// cv rejects the level when minEig < threshold or D < FLT_EPSILON.  lambda_min >= det / trace, so a
+// determinant well above trace * threshold settles the first test without the square root and
+// the division; the margins (1e-3 relative on the threshold, 1e-6 * trace^2 and 1e-6 * A11 * A22
+// absolute, i.e. > 10 ulp of every float rounding in either evaluation) keep the shortcut on the
+// safe side, and whatever it does not settle takes cv's own expression.
+__device__ __forceinline__ bool lk_reject_level(float A11, float A12, float A22, float& D, const LkParams& prm) {
+  const float P = A11 * A22;
+  D = P - A12 * A12;
+  const float T = A11 + A22;
+  bool reject = D < 1.1920928955078125e-7f;
+  if (!reject && !(2.f * D >= T * (prm.min_eig_c1 + 1e-6f * T) + 1e-6f * P)) {
+    const float minEig =
+        (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * prm.win * prm.win);
+    reject = (double)minEig < prm.min_eig_thr;
+  }
+  return reject;
+}
+
+// The J region [jx0, jx0 + 4 ndw) x [jy0, jy0 + rows) of level image Bb into LDS, in pair layout.
+template <int SEG>
+__device__ __forceinline__ void lk_stage_j(const uint8_t* __restrict__ Bb, int bp, int bw, int bh, int jx0, int jy0,
+                                           unsigned int* sJ, const LkSmem& L, int lane) {
+  constexpr int NJ = (SEG <= 8) ? 4 : 10;  // J-region staging tasks per lane (jmargin 3: 28 rows / 8; 38 / 4)
+  if (region_is_fast(Bb, bp, bw, bh, jx0, jy0, L.gj)) {
+    unsigned int rj[NJ];
+    region_load_regs<NJ>(rj, Bb, bp, jx0, jy0, L.gj, lane);
+    region_store_pairs<NJ>(sJ, rj, L.gj, L.jp_pitch, lane);
+  } else {
+    region_stage_slow_pairs<NJ>(sJ, Bb, bp, bw, bh, jx0, jy0, L.gj, L.jp_pitch, lane);
+  }
+}
+
+// One iteration's pixel work: the lane's share of b1 = sum Jw * Ix - cI1, b2 = sum Jw * Iy - cI2, with Jw the
+// bilinear sample of J at the lane's pixels.  p0 = the lane's first pixel in the pair region for this window
+// position; V0, V1 = packed weights (w00 | w01 << 16, w10 | w11 << 16); nonneg = (w11 >= 0).
+template <int SEG>
+__device__ __forceinline__ void lk_iter_pixels(const unsigned int* p0, int jp_pitch, unsigned int V0, unsigned int V1,
+                                               bool nonneg, const unsigned int (&IxP)[(SEG + 1) / 2],
+                                               const unsigned int (&IyP)[(SEG + 1) / 2], int cI1, int cI2, int& b1,
+                                               int& b2) {
+  constexpr int NP = (SEG + 1) / 2;
+  unsigned int R0[SEG], R1[SEG];
+#pragma unroll
+  for (int k = 0; k < SEG; k++) R0[k] = p0[k];
+#pragma unroll
+  for (int k = 0; k < SEG; k++) R1[k] = p0[jp_pitch + k];
+  int Jw[SEG + 1];
+  Jw[SEG] = 0;
+  {
+    int Jr[SEG];
+    if (nonneg) {
+#pragma unroll
+      for (int k = 0; k < SEG; k++) Jr[k] = udot2(R1[k], V1, udot2(R0[k], V0, (1 << (W_BITS - 5 - 1))));
+    } else {
+#pragma unroll
+      for (int k = 0; k < SEG; k++) Jr[k] = sdot2(R1[k], V1, sdot2(R0[k], V0, (1 << (W_BITS - 5 - 1))));
+    }
+#pragma unroll
+    for (int k = 0; k < SEG; k++) Jw[k] = Jr[k] >> (W_BITS - 5);  // 0 <= Jw <= 8160
+  }
+  b1 = -cI1;
+  b2 = -cI2;
+#pragma unroll
+  for (int k2 = 0; k2 < NP; k2++) {
+    const unsigned int jp = pack_lo16(Jw[2 * k2], Jw[2 * k2 + 1]);
+    b1 = sdot2(jp, IxP[k2], b1);
+    b2 = sdot2(jp, IyP[k2], b2);
+  }
+}
+
+// cv: dx*dx + dy*dy <= eps^2 evaluated in double.  The float value s is within 3 ulp of the
+// exact sum, so outside a 1e-6 relative band around eps^2 the float compare already decides.
+__device__ __forceinline__ bool lk_converged(float dx, float dy, const LkParams& prm) {
+  const float s = __fmaf_rn(dx, dx, dy * dy);
+  if (s <= prm.eps2_lo) return true;
+  if (s >= prm.eps2_hi) return false;
+  return (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2;
+}
+
+// Tracks one point from pyramid A (template, derivatives) to pyramid B.  One wave, wave-uniform control flow.
+// Returns the OpenCV status (true = found); out = nextPts.
+// SEG = compile-time pixels per lane (>= prm.seglen).
+template <int SEG>
+__device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, float ptx, float pty,
+                               float& outx, float& outy, const LkParams& prm, uint8_t* smem,
+                               const LkSmem& L) {
+  constexpr int NP = (SEG + 1) / 2;         // pixel pairs per lane
+  constexpr int NRAW = (SEG <= 8) ? 3 : 2;  // raw DPP steps of the exact sums (see wave_sums_exact_lds)
+  const int lane0 = threadIdx.x & 63;
+  const int win = prm.win;
+  uint8_t* sI = smem;
+  unsigned int* sJ = reinterpret_cast<unsigned int*>(smem + L.off_j);
+  long long* sAcc = reinterpret_cast<long long*>(smem + L.off_acc);
+  const float half = (float)(win - 1) * 0.5f;
+  const float FLT_SCALE = 1.f / (float)(1 << 20);
+  const int maxLevel = A.nlevels - 1;
+  bool status = true;
+  float nx = 0.f, ny = 0.f;  // nextPts
+
+  int jx0 = 0, jy0 = 0;
+
+  for (int level = maxLevel; level >= 0; level--) {
+    // An opaque zero, new in every level: whatever derives from (lane0 + oz) cannot be hoisted out of
+    // the level loop.  Hoisted, these dozen addresses and masks stay live through the whole kernel and
+    // push the 96-register build into scratch spills; recomputing them costs ~15 instructions a level.
+    int oz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+    const int lane = lane0 + oz;
+    const LkLaneMap m = lk_lane_map<SEG>(lane, prm, smem, L);
+    const float lscale = 1.f / (float)(1 << level);
+    float px = ptx * lscale, py = pty * lscale;
+    if (level == maxLevel) {
+      nx = px;
+      ny = py;
+    } else {
+      nx = nx * 2.f;
+      ny = ny * 2.f;
+    }
+    px -= half;
+    py -= half;
+    const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px));
+    const int ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
+    const int aw = A.w[level], ah = A.h[level];
+    const bool in_range = !(ipx < -win || ipx >= aw || ipy < -win || ipy >= ah);
+
+    if (in_range) lk_stage_i<SEG>(A, level, stream, ipx, ipy, sI, L, lane);
+    lk_wave_sync();
+    if (in_range) VSF_LKSTAT(level * 16 + 0);
+
+    const uint8_t* Bb = B.base[level] + (long long)stream * B.sstride[level];
+    const int bp = B.pitch[level], bw = B.w[level], bh = B.h[level];
+    bool level_ok = in_range;
+    if (!in_range && level == 0) status = false;
+
+    unsigned int IxP[NP], IyP[NP];  // template gradients, pair-packed, zero where the lane owns no pixel
+    int cI1 = 0, cI2 = 0;
+    float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
+    if (level_ok) {
+      const float fa = px - (float)ipx, fb = py - (float)ipy;
+      int iw00, iw01, iw10, iw11;
+      bilinear_weights_uniform(fa, fb, iw00, iw01, iw10, iw11);
+      // every tap of every window pixel lies inside the level image: no zero-padded gradient involved
+      const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < aw && ipy + win < ah;
+      int part[3];
+      lk_template<SEG>(smem, L, prm, m, lane, aw, ah, ipx, ipy, interior, iw00, iw01, iw10, iw11, IxP, IyP, cI1, cI2,
+                       part);
+      float Asum[3];
+#if VSF_SUM_LDS
+      wave_sums_exact_lds<3, NRAW>(part, Asum, sAcc, lane);
+#else
+      wave_sums_exact_f32<3>(part, Asum);
+#endif
+      A11 = Asum[0] * FLT_SCALE;
+      A12 = Asum[1] * FLT_SCALE;
+      A22 = Asum[2] * FLT_SCALE;
+      if (lk_reject_level(A11, A12, A22, D, prm)) {
+        if (level == 0) status = false;
+        level_ok = false;
+      }
+    }
+
+    if (level_ok) {
+      VSF_LKSTAT(level * 16 + 1);
+      int n_iter = 0, end_kind = 7;
+      D = 1.f / D;
+      bool staged = false;
+      float cx = nx - half, cy = ny - half;  // nextPt - halfWin
+      float pdx = 0.f, pdy = 0.f;
+      for (int j = 0; j < prm.max_count; j++) {
+        const int inx = __builtin_amdgcn_readfirstlane((int)floorf(cx));
+        const int iny = __builtin_amdgcn_readfirstlane((int)floorf(cy));
+        if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
+          if (level == 0) status = false;
+          end_kind = 8;
+          break;
+        }
+        n_iter++;
+        if (!staged || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + 4 * L.gj.ndw ||
+            iny + win + 1 > jy0 + L.gj.rows) {
+          lk_wave_sync();  // previous iteration's reads are done
+          jx0 = (inx - prm.jmargin) & ~3;
+          jy0 = iny - prm.jmargin;
+          lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
+          staged = true;
+          VSF_LKSTAT(level * 16 + 3);
+          lk_wave_sync();
+        }
+        int iw00, iw01, iw10, iw11;
+        bilinear_weights_uniform(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
+        int b1, b2;
+        {
+          // rowJ0 = sJ + rr * pitch + xx0 per lane; the rest of the address is wave-uniform
+          const unsigned int* p0 = m.rowJ0 + ((iny - jy0) * L.jp_pitch + (inx - jx0));
+          const unsigned int V0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
+          const unsigned int V1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
+          lk_iter_pixels<SEG>(p0, L.jp_pitch, V0, V1, iw11 >= 0, IxP, IyP, cI1, cI2, b1, b2);
+        }
+        float bsum[2];
+        {
+          const int part[2] = {b1, b2};
+#if VSF_SUM_LDS
+          wave_sums_exact_lds<2, NRAW>(part, bsum, sAcc, lane);
+#else
+          wave_sums_exact_f32<2>(part, bsum);
+#endif
+        }
+        const float fb1 = bsum[0] * FLT_SCALE, fb2 = bsum[1] * FLT_SCALE;
+        const float dx = (A12 * fb2 - A22 * fb1) * D;
+        const float dy = (A12 * fb1 - A11 * fb2) * D;
+        cx += dx;
+        cy += dy;
+        nx = cx + half;
+        ny = cy + half;
+        if (lk_converged(dx, dy, prm)) {
+          end_kind = 5;
+          break;
+        }
+        // cv compares the float sums with the double 0.01; (float)0.01 is the largest float below
+        // 0.01, so `<= 0.01f` in float is the same predicate
+        if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
+          nx -= dx * 0.5f;
+          ny -= dy * 0.5f;
+          end_kind = 6;
+          break;
+        }
+        pdx = dx;
+        pdy = dy;
+      }
+#ifdef VSF_LK_STATS
+      if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&g_lk_stats[level * 16 + 2], (unsigned long long)n_iter);
+        atomicAdd(&g_lk_stats[level * 16 + end_kind], 1ull);
+        atomicAdd(&g_lk_stats[128 + level * 32 + (n_iter < 31 ? n_iter : 31)], 1ull);
+      }
+#else
+      (void)n_iter;
+      (void)end_kind;
+#endif
+      // cv: with err requested (the reference always passes an err vector) the final position is
+      // range-checked once more at level 0
+      if (status && level == 0) {
+        const int fx = (int)floorf(nx - half), fy = (int)floorf(ny - half);
+        if (fx < -win || fx >= bw || fy < -win || fy >= bh) status = false;
+      }
+    }
+    lk_wave_sync();  // LDS is reused by the next level
+  }
+  outx = nx;
+  outy = ny;
+  return status;
+}
+
+// Fills the per-lane ownership masks in LDS (once per kernel): 16 bits per window pixel the lane owns.
+template <int SEG>
+__device__ __forceinline__ void lk_init_masks(const LkParams& prm, uint8_t* smem, const LkSmem& L) {
+  constexpr int NP = (SEG + 1) / 2;
+  const int lane = threadIdx.x & 63;
+  const int r = lane / prm.nseg;
+  const int x0 = (lane - r * prm.nseg) * prm.seglen;
+  const bool owner = (r < prm.win) && (x0 < prm.win);
+  const int cnt = owner ? min(prm.seglen, prm.win - x0) : 0;
+  unsigned int* m = reinterpret_cast<unsigned int*>(smem + L.off_mask) + lane * NP;
+#pragma unroll
+  for (int k2 = 0; k2 < NP; k2++)
+    m[k2] = (2 * k2 + 1 < cnt) ? 0xffffffffu : ((2 * k2 < cnt) ? 0x0000ffffu : 0u);
+  lk_wave_sync();
+}
+
+// flags bit0 = forward found, bit1 = backward found, bit2 = verified (kept).
+// ref: FeatureTrackerLucasKanade.cpp:36-80 (forward, backward on the forward survivors, then
+// ||back - original||_2 <= threshold in double against the ORIGINAL double position).
+template <int SEG>
+__global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
+                                                   const int* __restrict__ n, int cap, int fgrid, int nstreams,
+                                                   LkParams prm, float2* __restrict__ fwd,
+                                                   uint8_t* __restrict__ flags) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so all
+  // features of one stream are given to ONE residue class: their overlapping window lines are then
+  // fetched into a single L2 instead of eight.  Placement is a speed matter only.
+  // fgrid workgroups serve a stream; feature f0 + k * fgrid goes to workgroup f0 (k > 0 only when a
+  // table holds more than fgrid entries, which the usual table size never does).
+  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+  const int grp = local / fgrid;
+  const int stream = grp * 8 + xcd, f0 = local - grp * fgrid;
+  if (stream >= nstreams) return;
+  const int nf = n[stream];
+  if (f0 >= nf) return;
+  const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
+  lk_init_masks<SEG>(prm, smem, L);
+  for (int f = f0; f < nf; f += fgrid) {
+    const double2 p0 = xy[(long long)stream * cap + f];
+    const float p0x = (float)p0.x, p0y = (float)p0.y;  // :210 double -> float narrowing
+    float qx, qy;
+    uint8_t flag = 0;
+    if (lk_track_point<SEG>(P, C, stream, p0x, p0y, qx, qy, prm, smem, L)) {
+      flag |= 1;
+      float rx, ry;
+      if (lk_track_point<SEG>(C, P, stream, qx, qy, rx, ry, prm, smem, L)) {
+        flag |= 2;
+        const double ddx = (double)rx - p0.x, ddy = (double)ry - p0.y;
+        if (sqrt(ddx * ddx + ddy * ddy) <= prm.backtrack_thr) flag |= 4;
+      }
+    }
+    if ((threadIdx.x & 63) == 0) {
+      fwd[(long long)stream * cap + f] = make_float2(qx, qy);
+      flags[(long long)stream * cap + f] = flag;
+    }
+  }
+}
+
+// plain cv::calcOpticalFlowPyrLK on a point list (parity tests): one wave per point
+template <int SEG>
+__global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_points_kernel(PyrView P, PyrView C, const float2* __restrict__ pts,
+                                                       int n, LkParams prm, float2* __restrict__ out,
+                                                       uint8_t* __restrict__ status) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  const int f = blockIdx.x;
+  if (f >= n) return;
+  const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
+  lk_init_masks<SEG>(prm, smem, L);
+  const float2 p = pts[f];
+  float qx, qy;
+  const bool st = lk_track_point<SEG>(P, C, 0, p.x, p.y, qx, qy, prm, smem, L);
+  if ((threadIdx.x & 63) == 0) {
+    out[f] = make_float2(qx, qy);
+    status[f] = st ? 1 : 0;
+  }
+}
+
+}  // namespace vsf
