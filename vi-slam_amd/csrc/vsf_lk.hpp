@@ -804,7 +804,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
     const int lane = lane0 + oz;
     const LkLaneMap m = lk_lane_map<SEG>(lane, prm, smem, L);
-    const float lscale = 1.f / (float)(1 << level);
+    const float lscale = __int_as_float((127 - level) << 23);  // (float)(1.0 / 2^level), exact, no division
     float px = ptx * lscale, py = pty * lscale;
     if (level == maxLevel) {
       nx = px;
@@ -815,8 +815,10 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     }
     px -= half;
     py -= half;
-    const int ipx = __builtin_amdgcn_readfirstlane((int)floorf(px));
-    const int ipy = __builtin_amdgcn_readfirstlane((int)floorf(py));
+    // the floor as a float serves the fraction below: (float)ip == floorf(p) wherever the point is in range
+    const float fpx = floorf(px), fpy = floorf(py);
+    const int ipx = __builtin_amdgcn_readfirstlane((int)fpx);
+    const int ipy = __builtin_amdgcn_readfirstlane((int)fpy);
     const int aw = A.w[level], ah = A.h[level];
     const bool in_range = !(ipx < -win || ipx >= aw || ipy < -win || ipy >= ah);
 
@@ -833,7 +835,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     int cI1 = 0, cI2 = 0;
     float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
     if (level_ok) {
-      const float fa = px - (float)ipx, fb = py - (float)ipy;
+      const float fa = px - fpx, fb = py - fpy;
       int iw00, iw01, iw10, iw11;
       bilinear_weights_uniform(fa, fb, iw00, iw01, iw10, iw11);
       // every tap of every window pixel lies inside the level image: no zero-padded gradient involved
@@ -864,8 +866,9 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       float cx = nx - half, cy = ny - half;  // nextPt - halfWin
       float pdx = 0.f, pdy = 0.f;
       for (int j = 0; j < prm.max_count; j++) {
-        const int inx = __builtin_amdgcn_readfirstlane((int)floorf(cx));
-        const int iny = __builtin_amdgcn_readfirstlane((int)floorf(cy));
+        const float fcx = floorf(cx), fcy = floorf(cy);
+        const int inx = __builtin_amdgcn_readfirstlane((int)fcx);
+        const int iny = __builtin_amdgcn_readfirstlane((int)fcy);
         if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
           if (level == 0) status = false;
           end_kind = 8;
@@ -883,7 +886,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           lk_wave_sync();
         }
         int iw00, iw01, iw10, iw11;
-        bilinear_weights_uniform(cx - (float)inx, cy - (float)iny, iw00, iw01, iw10, iw11);
+        bilinear_weights_uniform(cx - fcx, cy - fcy, iw00, iw01, iw10, iw11);
         int b1, b2;
         {
           // rowJ0 = sJ + rr * pitch + xx0 per lane; the rest of the address is wave-uniform
