@@ -124,6 +124,15 @@ int vsf_detect(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t s
                const uint8_t* mask, int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age,
                int32_t* n_inout, int32_t capacity);
 
+/* Track, then UpdateDetection on the SAME frame -- the loop body of the reference's example
+ * (example/vslam/example_feature_detection_and_tracking.cpp:43-55) -- as one call: the frame crosses PCIe once, the
+ * table once in each direction, one synchronisation.  Identical results to vsf_track followed by vsf_detect.
+ * (KimeraFrontend runs RemoveOutlier between the two on keyframes, KimeraFrontend.cpp:306-335: use the two calls
+ * there.)  mask may be NULL; stats may be NULL. */
+int vsf_step(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride, const uint8_t* mask,
+             int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout, int32_t capacity,
+             vsf_track_stats* stats);
+
 /* max_feature_index_ of the detector (FeatureDetectorShiTomasiBucketing.hpp:53). */
 int vsf_get_max_feature_index(vsf_ctx* ctx, int32_t stream, uint64_t* out);
 int vsf_set_max_feature_index(vsf_ctx* ctx, int32_t stream, uint64_t value);

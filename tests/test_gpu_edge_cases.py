@@ -201,3 +201,32 @@ def test_refused_configurations(vsf):
     assert big.detect(img, ids, xy, age, 0) > 200
     small.close()
     big.close()
+
+
+def test_vsf_step_equals_track_then_detect(vsf, oracle, synth):
+    """vsf_step (one upload, one table round trip) against vsf_track + vsf_detect on separate contexts and against
+    the oracle, with a mask and a strided frame, over a sequence."""
+    w, h = 400, 300
+    frames, _ = synth.sequence(61, w, h, 5)
+    mask = np.ones((h, w), np.uint8)
+    mask[:, :60] = 0
+    wide = np.zeros((5, h, w + 16), np.uint8)
+    wide[:, :, 3:3 + w] = frames
+    kw = dict(grid_rows=3, grid_cols=2, max_features=150, min_distance=6.0, klt_win=15, klt_max_level=2, width=w, height=h,
+              capacity=256)
+    one = vsf.Context(vsf.default_params(**kw))
+    det = vsf.FeatureDetectorShiTomasiBucketing(3, 2, 150, 6.0, w, h, capacity=256)
+    trk = vsf.FeatureTrackerLucasKanade(30, 0.01, 15, 2, 1.0, w, h, capacity=256)
+    a, b = vsf.FeatureDatabase(256), vsf.FeatureDatabase(256)
+    odet, otrk, T = oracle.Detector(3, 2, 150, 6.0), oracle.Tracker(30, 0.01, 15, 2, 1.0, oracle.ACC_EXACT), oracle.FeatureTable(256)
+    for k in range(5):
+        a.n, stats = one.step(wide[k, :, 3:3 + w], a.ids, a.xy, a.age, a.n, mask)
+        trk.Track(b, frames[k])
+        det.UpdateDetection(b, frames[k], mask)
+        otrk.track(T, frames[k])
+        odet.update_detection(T, frames[k], mask)
+        assert a.as_dict() == b.as_dict() == T.as_dict(), "frame %d" % k
+        if k:
+            assert tuple(stats) == tuple(trk.last_stats)
+    assert a.n > 50
+    one.close()

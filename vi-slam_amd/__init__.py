@@ -22,7 +22,7 @@ KERNEL_NAMES = ["pyramid", "lk", "compact", "occupancy", "score", "candidates", 
 # every symbol include/vsf.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = [
     "vsf_default_params", "vsf_create", "vsf_destroy", "vsf_last_error", "vsf_version",
-    "vsf_track", "vsf_track_pair", "vsf_detect", "vsf_get_max_feature_index",
+    "vsf_track", "vsf_track_pair", "vsf_detect", "vsf_step", "vsf_get_max_feature_index",
     "vsf_set_max_feature_index", "vsf_batch_track", "vsf_batch_detect", "vsf_batch_step",
     "vsf_batch_upload", "vsf_batch_download", "vsf_batch_device_tables", "vsf_batch_status",
     "vsf_batch_export_tracks",
@@ -196,6 +196,20 @@ class Context:
         self._chk(lib().vsf_detect(self._h, _vp(img), w, h, stride, mptr, mstride, _vp(ids), _vp(xy),
                                    _vp(age), C.byref(nn), len(ids)))
         return nn.value
+
+    def step(self, img, ids, xy, age, n, mask=None):
+        """Track, then UpdateDetection on the same frame in one call (vsf_step)."""
+        img, stride = self._frame(img)
+        h, w = img.shape
+        nn = C.c_int32(n)
+        st = VsfTrackStats()
+        mptr, mstride = None, 0
+        if mask is not None:
+            mask, mstride = self._frame(mask)
+            mptr = _vp(mask)
+        self._chk(lib().vsf_step(self._h, _vp(img), w, h, stride, mptr, mstride, _vp(ids), _vp(xy), _vp(age),
+                                 C.byref(nn), len(ids), C.byref(st)))
+        return nn.value, (st.input, st.forward, st.backward, st.verified)
 
     def get_max_feature_index(self, stream=0):
         v = C.c_uint64()

@@ -49,7 +49,8 @@ struct vsf_ctx {
   int cur = 0;
   bool has_prev = false;
   uint8_t* own_frame[2] = {};  // host-API staging of stream 0 (ping-pong: previous frame stays resident)
-  uint8_t* h_stage = nullptr;  // pinned host buffer for strided host frames, allocated on first use
+  uint8_t* h_stage = nullptr;  // pinned host block of the host-pointer API: frame | mask | table pack (first use)
+  uint8_t* d_pack = nullptr;   // device side of the table pack
   // stateless pair / debug buffers (single stream), allocated lazily
   PyrSet pair_pyr[2];
   uint8_t* pair_frame[2] = {};
@@ -546,39 +547,81 @@ void host_grid(int w, int h, int cols, int rows, std::vector<int4>& rects, std::
     }
 }
 
-// Host frame -> device, rows packed.  A contiguous frame goes in one 1-D copy; a strided one is packed
-// into a pinned staging buffer first (hipMemcpy2D from pageable memory copies row by row: 4.5 ms for a
-// 752x480 frame, measured, against ~0.1 ms this way).
-int upload_frame(vsf_ctx* c, uint8_t* dst, const uint8_t* img, int w, int h, int stride) {
-  if (stride == w) {
-    HIPCHK(c, hipMemcpy(dst, img, (size_t)w * h, hipMemcpyHostToDevice));
-    return VSF_OK;
-  }
-  if (!c->h_stage) HIPCHK(c, hipHostMalloc((void**)&c->h_stage, (size_t)c->p.width * c->p.height, hipHostMallocDefault));
-  for (int y = 0; y < h; y++) memcpy(c->h_stage + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
-  HIPCHK(c, hipMemcpy(dst, c->h_stage, (size_t)w * h, hipMemcpyHostToDevice));
+// Host-pointer API staging.  Everything a call moves goes through ONE pinned host block (frame | mask | table
+// pack) with asynchronous copies on the default stream and a single synchronisation at the end of the call: a
+// 752x480 frame from pageable memory, four table copies up and four down cost 0.49 ms per Track + UpdateDetection
+// before (round 1); hipMemcpy2D from pageable memory copies row by row (4.5 ms per frame, measured).
+int ensure_stage(vsf_ctx* c) {
+  if (c->h_stage) return VSF_OK;
+  const size_t fs = (size_t)c->p.width * c->p.height;
+  HIPCHK(c, hipHostMalloc((void**)&c->h_stage, 2 * fs + table_pack_bytes(c->cap) + 64, hipHostMallocDefault));
+  return dalloc(c, &c->d_pack, table_pack_bytes(c->cap));
+}
+
+// slot 0 = frame, 1 = mask
+int upload_frame(vsf_ctx* c, uint8_t* dst, const uint8_t* img, int w, int h, int stride, int slot = 0) {
+  int rc = ensure_stage(c);
+  if (rc) return rc;
+  uint8_t* hp = c->h_stage + (size_t)slot * c->p.width * c->p.height;
+  if (stride == w)
+    memcpy(hp, img, (size_t)w * h);
+  else
+    for (int y = 0; y < h; y++) memcpy(hp + (size_t)y * w, img + (size_t)y * stride, (size_t)w);
+  HIPCHK(c, hipMemcpyAsync(dst, hp, (size_t)w * h, hipMemcpyHostToDevice, nullptr));
   return VSF_OK;
 }
 
+uint8_t* host_pack(vsf_ctx* c) { return c->h_stage + 2 * (size_t)c->p.width * c->p.height; }
+
+// the caller's table -> stream 0 of the device table (one copy + one small kernel); also clears the status word
 int upload_table0(vsf_ctx* c, const uint64_t* ids, const double* xy, const uint32_t* age, int n) {
   if (n < 0 || n > c->cap) return fail(c, VSF_E_CAPACITY, "table of %d entries exceeds capacity %d", n, c->cap);
+  int rc = ensure_stage(c);
+  if (rc) return rc;
+  uint8_t* hp = host_pack(c);
+  memset(hp, 0, 64);
+  reinterpret_cast<int*>(hp)[0] = n;
   if (n > 0) {
-    HIPCHK(c, hipMemcpy(c->d_ids, ids, (size_t)n * 8, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_xy, xy, (size_t)n * 16, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_age, age, (size_t)n * 4, hipMemcpyHostToDevice));
+    memcpy(hp + 64, xy, (size_t)n * 16);
+    memcpy(hp + 64 + (size_t)c->cap * 16, ids, (size_t)n * 8);
+    memcpy(hp + 64 + (size_t)c->cap * 24, age, (size_t)n * 4);
   }
-  HIPCHK(c, hipMemcpy(c->d_n, &n, 4, hipMemcpyHostToDevice));
+  // three ranges of the pack hold data; below ~64 KB one copy of the whole block is cheaper than three
+  HIPCHK(c, hipMemcpyAsync(c->d_pack, hp, table_pack_bytes(c->cap), hipMemcpyHostToDevice, nullptr));
+  hipLaunchKernelGGL(table_unpack_kernel, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, nullptr, c->d_pack,
+                     c->cap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->d_status);
+  HIPCHK(c, hipGetLastError());
   return VSF_OK;
 }
 
-int download_table0(vsf_ctx* c, uint64_t* ids, double* xy, uint32_t* age, int* n, int capacity) {
-  int m = 0;
-  HIPCHK(c, hipMemcpy(&m, c->d_n, 4, hipMemcpyDeviceToHost));
+// stream 0 of the device table -> the pinned pack (asynchronous; read it with read_table0 after a synchronisation)
+int download_table0_async(vsf_ctx* c) {
+  int rc = ensure_stage(c);
+  if (rc) return rc;
+  hipLaunchKernelGGL(table_pack_kernel, dim3((c->cap + 255) / 256), dim3(256), 0, nullptr, c->d_ids, c->d_xy, c->d_age, c->d_n,
+                     c->d_stats, c->d_status, c->cap, c->d_pack);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(host_pack(c), c->d_pack, table_pack_bytes(c->cap), hipMemcpyDeviceToHost, nullptr));
+  return VSF_OK;
+}
+
+int read_table0(vsf_ctx* c, uint64_t* ids, double* xy, uint32_t* age, int* n, int capacity, vsf_track_stats* stats,
+                int* status) {
+  const uint8_t* hp = host_pack(c);
+  const int* hdr = reinterpret_cast<const int*>(hp);
+  const int m = hdr[0];
+  if (status) *status = hdr[5];
+  if (stats) {
+    stats->input = hdr[1];
+    stats->forward = hdr[2];
+    stats->backward = hdr[3];
+    stats->verified = hdr[4];
+  }
   if (m > capacity) return fail(c, VSF_E_CAPACITY, "result of %d entries exceeds caller capacity %d", m, capacity);
   if (m > 0) {
-    HIPCHK(c, hipMemcpy(ids, c->d_ids, (size_t)m * 8, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(xy, c->d_xy, (size_t)m * 16, hipMemcpyDeviceToHost));
-    HIPCHK(c, hipMemcpy(age, c->d_age, (size_t)m * 4, hipMemcpyDeviceToHost));
+    memcpy(xy, hp + 64, (size_t)m * 16);
+    memcpy(ids, hp + 64 + (size_t)c->cap * 16, (size_t)m * 8);
+    memcpy(age, hp + 64 + (size_t)c->cap * 24, (size_t)m * 4);
   }
   *n = m;
   return VSF_OK;
@@ -668,6 +711,7 @@ void vsf_destroy(vsf_ctx* c) {
     if (c->pair_frame[i]) (void)hipFree(c->pair_frame[i]);
   }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
+  if (c->d_pack) (void)hipFree(c->d_pack);
   void* lssd_bufs[] = {c->d_lssd_ids, c->d_lssd_xy, c->d_lssd_n};
   for (void* b : lssd_bufs)
     if (b) (void)hipFree(b);
@@ -969,23 +1013,21 @@ int vsf_track(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stri
   HIPCHK(c, hipSetDevice(c->p.device_id));
   const int n = *n_inout;
   if (n > 0 && (!ids || !xy || !age)) return VSF_E_INVALID;
+  if (n < 0 || n > c->cap) return fail(c, VSF_E_CAPACITY, "table of %d entries exceeds capacity %d", n, c->cap);
   uint8_t* slot = c->own_frame[c->cur ^ 1];
   rc = upload_frame(c, slot, img, w, h, stride);
   if (rc) return rc;
   const bool first = !c->has_prev;
-  rc = upload_table0(c, ids, xy, age, n);
-  if (rc) return rc;
-  rc = track_impl(c, own_ref(c, slot), 1, nullptr);
+  if (!first) rc = upload_table0(c, ids, xy, age, n);
+  if (!rc) rc = track_impl(c, own_ref(c, slot), 1, nullptr);
+  if (!rc && !first) rc = download_table0_async(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(nullptr));
   if (first) {  // :29-32 table untouched
     if (stats) stats->input = stats->forward = stats->backward = stats->verified = n;
     return VSF_OK;
   }
-  rc = download_table0(c, ids, xy, age, n_inout, n);
-  if (rc) return rc;
-  if (stats) HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(*stats), hipMemcpyDeviceToHost));
-  return VSF_OK;
+  return read_table0(c, ids, xy, age, n_inout, n, stats, nullptr);
 }
 
 int vsf_track_pair(vsf_ctx* c, const uint8_t* prev, int32_t prev_stride, const uint8_t* cur, int32_t cur_stride,
@@ -1002,7 +1044,7 @@ int vsf_track_pair(vsf_ctx* c, const uint8_t* prev, int32_t prev_stride, const u
   if (n > 0 && (!ids || !xy || !age)) return VSF_E_INVALID;
   rc = ensure_pair(c);
   if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, prev_stride);
-  if (!rc) rc = upload_frame(c, c->pair_frame[1], cur, w, h, cur_stride);
+  if (!rc) rc = upload_frame(c, c->pair_frame[1], cur, w, h, cur_stride, 1);
   if (!rc) rc = upload_table0(c, ids, xy, age, n);
   if (rc) return rc;
   const FrameRef fp = own_ref(c, c->pair_frame[0]), fc = own_ref(c, c->pair_frame[1]);
@@ -1010,12 +1052,10 @@ int vsf_track_pair(vsf_ctx* c, const uint8_t* prev, int32_t prev_stride, const u
   if (!rc) rc = build_pyramid(c, fc, c->pair_pyr[1], 1, nullptr);
   if (!rc) rc = launch_lk_fb(c, make_view(c, fp, c->pair_pyr[0]), make_view(c, fc, c->pair_pyr[1]), 1, nullptr);
   if (!rc) rc = launch_compact(c, 1, nullptr);
+  if (!rc) rc = download_table0_async(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(nullptr));
-  rc = download_table0(c, ids, xy, age, n_inout, n);
-  if (rc) return rc;
-  if (stats) HIPCHK(c, hipMemcpy(stats, c->d_stats, sizeof(*stats), hipMemcpyDeviceToHost));
-  return VSF_OK;
+  return read_table0(c, ids, xy, age, n_inout, n, stats, nullptr);
 }
 
 int vsf_detect(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, const uint8_t* mask,
@@ -1026,18 +1066,44 @@ int vsf_detect(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t str
   if (mask && mask_stride < w) return VSF_E_INVALID;
   HIPCHK(c, hipSetDevice(c->p.device_id));
   rc = upload_frame(c, c->det_frame, img, w, h, stride);
-  if (!rc && mask) rc = upload_frame(c, c->det_mask, mask, w, h, mask_stride);
-  if (!rc) rc = upload_table0(c, ids, xy, age, *n_inout);
-  if (rc) return rc;
-  int zero = 0;
-  HIPCHK(c, hipMemcpy(c->d_status, &zero, 4, hipMemcpyHostToDevice));
-  rc = detect_impl(c, own_ref(c, c->det_frame), mask ? c->det_mask : nullptr, (long long)w * h, w, 1, nullptr);
+  if (!rc && mask) rc = upload_frame(c, c->det_mask, mask, w, h, mask_stride, 1);
+  if (!rc) rc = upload_table0(c, ids, xy, age, *n_inout);  // also clears the status word
+  if (!rc) rc = detect_impl(c, own_ref(c, c->det_frame), mask ? c->det_mask : nullptr, (long long)w * h, w, 1, nullptr);
+  if (!rc) rc = download_table0_async(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(nullptr));
   int st = 0;
-  HIPCHK(c, hipMemcpy(&st, c->d_status, 4, hipMemcpyDeviceToHost));
-  rc = download_table0(c, ids, xy, age, n_inout, capacity);
+  rc = read_table0(c, ids, xy, age, n_inout, capacity, nullptr, &st);
   if (rc) return rc;
+  if (st) return fail(c, st, "feature table capacity %d exhausted during detection", c->cap);
+  return VSF_OK;
+}
+
+// Track, then UpdateDetection on the same frame (the loop of example_feature_detection_and_tracking.cpp:43-55) with
+// ONE frame upload, one table round trip and one synchronisation.
+int vsf_step(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, const uint8_t* mask,
+             int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout, int32_t capacity,
+             vsf_track_stats* stats) {
+  if (!c || !img || !n_inout || !ids || !xy || !age) return VSF_E_INVALID;
+  int rc = check_geom(c, w, h, stride);
+  if (rc) return rc;
+  if (mask && mask_stride < w) return VSF_E_INVALID;
+  HIPCHK(c, hipSetDevice(c->p.device_id));
+  const int n = *n_inout;
+  uint8_t* slot = c->own_frame[c->cur ^ 1];
+  const bool first = !c->has_prev;
+  rc = upload_frame(c, slot, img, w, h, stride);
+  if (!rc && mask) rc = upload_frame(c, c->det_mask, mask, w, h, mask_stride, 1);
+  if (!rc) rc = upload_table0(c, ids, xy, age, n);
+  if (!rc) rc = track_impl(c, own_ref(c, slot), 1, nullptr);
+  if (!rc) rc = detect_impl(c, own_ref(c, slot), mask ? c->det_mask : nullptr, (long long)w * h, w, 1, nullptr);
+  if (!rc) rc = download_table0_async(c);
+  if (rc) return rc;
+  HIPCHK(c, hipStreamSynchronize(nullptr));
+  int st = 0;
+  rc = read_table0(c, ids, xy, age, n_inout, capacity, first ? nullptr : stats, &st);
+  if (rc) return rc;
+  if (first && stats) stats->input = stats->forward = stats->backward = stats->verified = n;
   if (st) return fail(c, st, "feature table capacity %d exhausted during detection", c->cap);
   return VSF_OK;
 }
@@ -1167,7 +1233,7 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
   HIPCHK(c, hipSetDevice(c->p.device_id));
   rc = ensure_pair(c);
   if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, w);
-  if (!rc) rc = upload_frame(c, c->pair_frame[1], next, w, h, w);
+  if (!rc) rc = upload_frame(c, c->pair_frame[1], next, w, h, w, 1);
   if (rc) return rc;
   float2 *d_in = nullptr, *d_out = nullptr;
   uint8_t* d_st = nullptr;
@@ -1410,7 +1476,7 @@ int vsf_debug_lssd(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t
   HIPCHK(c, hipSetDevice(c->p.device_id));
   rc = lssd_ensure_pair(c);
   if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, w);
-  if (!rc) rc = upload_frame(c, c->pair_frame[1], next, w, h, w);
+  if (!rc) rc = upload_frame(c, c->pair_frame[1], next, w, h, w, 1);
   if (rc) return rc;
   float2 *d_in = nullptr, *d_out = nullptr;
   uint8_t* d_ok = nullptr;

@@ -1001,6 +1001,55 @@ __global__ __launch_bounds__(256) void unproject_kernel(const double2* __restric
   valid[i] = ok ? 1 : 0;
 }
 
+// Host-pointer API staging (vsf_track / vsf_detect / vsf_step, stream 0): the table crosses PCIe as ONE packed block
+// per direction instead of four copies.  Layout: int hdr[16] {n, stats[4], status} | double2 xy[cap] | u64 ids[cap]
+// | u32 age[cap].
+__host__ __device__ inline size_t table_pack_bytes(int cap) { return 64 + (size_t)cap * 28; }
+
+__global__ __launch_bounds__(256) void table_unpack_kernel(const uint8_t* __restrict__ pack, int cap,
+                                                           uint64_t* __restrict__ ids, double2* __restrict__ xy,
+                                                           uint32_t* __restrict__ age, int* __restrict__ n,
+                                                           int* __restrict__ status) {
+  const int* hdr = reinterpret_cast<const int*>(pack);
+  const double2* pxy = reinterpret_cast<const double2*>(pack + 64);
+  const uint64_t* pid = reinterpret_cast<const uint64_t*>(pack + 64 + (size_t)cap * 16);
+  const uint32_t* pag = reinterpret_cast<const uint32_t*>(pack + 64 + (size_t)cap * 24);
+  const int m = hdr[0];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+    xy[i] = pxy[i];
+    ids[i] = pid[i];
+    age[i] = pag[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    n[0] = m;
+    status[0] = 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void table_pack_kernel(const uint64_t* __restrict__ ids, const double2* __restrict__ xy,
+                                                         const uint32_t* __restrict__ age, const int* __restrict__ n,
+                                                         const int* __restrict__ stats, const int* __restrict__ status,
+                                                         int cap, uint8_t* __restrict__ pack) {
+  int* hdr = reinterpret_cast<int*>(pack);
+  double2* pxy = reinterpret_cast<double2*>(pack + 64);
+  uint64_t* pid = reinterpret_cast<uint64_t*>(pack + 64 + (size_t)cap * 16);
+  uint32_t* pag = reinterpret_cast<uint32_t*>(pack + 64 + (size_t)cap * 24);
+  const int m = min(n[0], cap);
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+    pxy[i] = xy[i];
+    pid[i] = ids[i];
+    pag[i] = age[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    hdr[0] = n[0];
+    hdr[1] = stats[0];
+    hdr[2] = stats[1];
+    hdr[3] = stats[2];
+    hdr[4] = stats[3];
+    hdr[5] = status[0];
+  }
+}
+
 // Fixed-size track records for the end-of-step collective over xGMI: 24 bytes,
 // padded to the table capacity so every rank contributes the same byte count.
 struct TrackRecord {
