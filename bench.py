@@ -288,15 +288,19 @@ def main():
         if args.tracker == "lk" and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("streams") == B and tj.get("config", "C2") == args.config:
+                if tj.get("streams") == B and tj.get("config_name", "C2") == args.config:
                     traffic = tj.get("hbm_bytes_per_launch")
                     if tj.get("valu_insts_per_launch") and lk_n:
                         # the kernel is bound by vector-instruction issue, not bytes: committed SQ_INSTS_VALU count
                         # per launch over the live launch time, against one wave64 VALU instruction per 2 cycles
                         # per SIMD (4 SIMDs x 256 CUs x 2.4 GHz, MI355X_MICROARCH.md)
                         rate = tj["valu_insts_per_launch"] / lk_avg
+                        # measured beside it (scratch/ubench/valu.hip, profiles/r02_valu_ubench.txt): independent integer /
+                        # dot2 / DPP wave64 instructions issue every 4.5 cycles per SIMD at 4 waves per SIMD on this part
+                        meas = 256 * 4 * 2.4e9 / 4.5
                         valu = {"insts_per_launch": tj["valu_insts_per_launch"], "achieved_ginst_s": rate / 1e9,
-                                "peak_ginst_s": VALU_PEAK / 1e9, "frac": rate / VALU_PEAK}
+                                "peak_ginst_s": VALU_PEAK / 1e9, "frac": rate / VALU_PEAK,
+                                "measured_int_issue_ginst_s": meas / 1e9, "frac_of_measured": rate / meas}
             except Exception:
                 traffic = None
         line = {

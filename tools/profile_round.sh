@@ -9,7 +9,7 @@ out=gpurun_out
 rm -rf /tmp/prof_$tag && mkdir -p /tmp/prof_$tag
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag/stats -- python3 bench.py --no-cpu > $out/prof_${tag}_bench.log 2>&1 || exit 1
 f=$(find /tmp/prof_$tag/stats -name '*kernel_stats.csv' | head -1)
-grep -v "at::native\|igemm\|Cijk\|elementwise\|rocprim" "$f" > $out/prof_${tag}_kernel_stats.csv
+grep "^\"Name\"\|vsf::" "$f" > $out/prof_${tag}_kernel_stats.csv
 for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_ACTIVE_INST_VALU SQ_INSTS_SMEM"; do
   name=$(echo $grp | cut -d' ' -f1)
   timeout -s KILL 180 rocprofv3 --pmc $grp --output-format csv -d /tmp/prof_$tag/$name -- python3 bench.py --steps 3 --warmup 2 --no-cpu > $out/prof_${tag}_pmc_$name.log 2>&1 || exit 1

@@ -21,8 +21,8 @@ def sq(counter):
     return None
 P = 752 * 480 + 376 * 240 + 188 * 120 + 94 * 60
 out = {
-    "kernel": name.replace("void vsf::", ""), "streams": streams,
-    "config": "C2 752x480, 4 levels, 21x21, ~285 features/stream",
+    "kernel": name.replace("void vsf::", ""), "streams": streams, "config_name": "C2",
+    "config": "C2 752x480, 4 levels, 21x21, ~245 features/stream, 6 % of every frame under moving occluders",
     "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
     "hbm_bytes_per_launch": int((f + w) * 1024),
     "algorithmic_bytes_per_launch": (2 * P + 24 * 300) * streams,
@@ -36,7 +36,7 @@ out = {
                   "run (byte loads, known traffic): FETCH_SIZE over the 3 levels = 536 MB vs 485 MB source bytes + "
                   "~12 % tile-halo re-reads = 543 MB, i.e. factor 1.0.",
     "note": "XCD-aware block mapping keeps each stream's windows in one L2 (2,911,273 KB fetched per launch before "
-            "it). Traffic stays below the algorithmic bytes because only the feature windows of each "
+            "it, round 1). Traffic stays below the algorithmic bytes because only the feature windows of each "
             "pyramid are touched; writes are the 9-byte-per-feature results (no register-spill scratch).",
 }
 json.dump(out, open(os.path.join(root, "profiles", "lk_traffic.json"), "w"), indent=1)

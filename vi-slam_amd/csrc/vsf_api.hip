@@ -751,7 +751,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   int anms_k = 0;
   if (use_anms) {
     anms_k = p->anms_detection_features > 0 ? p->anms_detection_features : 2 * p->max_features;
-    if (anms_k < 1 || anms_k > 2048 || (int)p->min_distance > ANMS_MAX_RADIUS || (int)p->min_distance < 0)
+    if (anms_k < 1 || anms_k > 4096 || (int)p->min_distance > ANMS_MAX_RADIUS || (int)p->min_distance < 0)
       return VSF_E_INVALID;
     if (p->anms_block_size != 3 && p->anms_block_size != 4) return VSF_E_INVALID;
     if (!(p->anms_quality_level >= 0.0) || p->anms_quality_level > 1.0 || !(p->anms_tolerance >= 0.0) ||
@@ -961,7 +961,10 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     acc(raise_dynamic_lds(reinterpret_cast<const void*>(occupancy_kernel), 0, occ_sm));
     acc(raise_dynamic_lds(reinterpret_cast<const void*>(select_kernel), 1, sel_sm));
     acc(raise_dynamic_lds(reinterpret_cast<const void*>(append_kernel), 2, app_sm));
-    if (use_anms) acc(raise_dynamic_lds(reinterpret_cast<const void*>(anms_ssc_kernel), 3, anms_ssc_smem(c->anms)));
+    if (use_anms) {
+      acc(raise_dynamic_lds(reinterpret_cast<const void*>(anms_ssc_kernel), 3, anms_ssc_smem(c->anms)));
+      acc(raise_dynamic_lds(reinterpret_cast<const void*>(anms_topk_kernel), 4, c->anms.kcap * 8));
+    }
     if (use_anms) {
       const int4 r = make_int4(0, 0, p->width, p->height);
       const float2 o = make_float2(0.f, 0.f);

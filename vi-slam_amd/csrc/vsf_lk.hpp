@@ -783,7 +783,6 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
                                const LkSmem& L) {
   constexpr int NP = (SEG + 1) / 2;         // pixel pairs per lane
   constexpr int NRAW = (SEG <= 8) ? 3 : 2;  // raw DPP steps of the exact sums (see wave_sums_exact_lds)
-  const int lane0 = threadIdx.x & 63;
   const int win = prm.win;
   uint8_t* sI = smem;
   unsigned int* sJ = reinterpret_cast<unsigned int*>(smem + L.off_j);
@@ -802,7 +801,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     // push the 96-register build into scratch spills; recomputing them costs ~15 instructions a level.
     int oz;
     asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
-    const int lane = lane0 + oz;
+    const int lane = (int)(threadIdx.x & 63) + oz;
     const LkLaneMap m = lk_lane_map<SEG>(lane, prm, smem, L);
     const float lscale = __int_as_float((127 - level) << 23);  // (float)(1.0 / 2^level), exact, no division
     float px = ptx * lscale, py = pty * lscale;
