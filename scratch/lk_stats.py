@@ -36,7 +36,7 @@ L.vsf_debug_lk_stats(buf, 0)
 s = np.array(list(buf), np.int64)
 out = {"streams": B, "occlusion": occ, "steps": steps, "levels": []}
 names = ["entered", "passed_min_eig", "iterations", "j_stagings", "interior_setups", "end_eps", "end_oscillation",
-         "end_max_count", "end_left_image"]
+         "end_max_count", "end_left_image", "cached_setups"]
 for lv in range(4):
     d = {n: int(s[lv * 16 + k]) for k, n in enumerate(names)}
     d["mean_iterations"] = d["iterations"] / max(1, d["passed_min_eig"])

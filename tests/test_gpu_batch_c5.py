@@ -143,3 +143,57 @@ def test_north_star_tolerance_against_reference_order(vsf, oracle, synth, w, h, 
         det.UpdateDetection(db, frames[k])
     assert total > 0.5 * maxn * (T - 1)
     assert worst <= 0.01, "worst deviation %.5f px over %d tracks" % (worst, total)
+
+
+def test_template_cache_invalidation(vsf, oracle, synth):
+    """The LK template cache (vsf_lk.hpp) must never serve an entry whose position, slot or image is not the one it
+    was built for: tables rewritten from the host between steps (moved, dropped and reordered entries), a tracker
+    reset, track-only steps, a frame passed twice -- every table bit for bit against per-stream oracles."""
+    import torch
+    w, h, B, T = 400, 300, 9, 9
+    frames = np.stack([synth.sequence(5000 + b, w, h, T)[0] for b in range(B)], 1)
+    det_args, trk_args = (2, 3, 150, 7.0), (30, 0.01, 21, 3, 1.0)
+    p = vsf.default_params(grid_rows=2, grid_cols=3, max_features=150, min_distance=7.0, klt_win=21, klt_max_level=3,
+                           width=w, height=h, streams=B, capacity=256)
+    ctx = vsf.Context(p)
+    dev = torch.from_numpy(frames).cuda()
+    dets = [oracle.Detector(*det_args) for _ in range(B)]
+    trks = [oracle.Tracker(*trk_args, oracle.ACC_EXACT) for _ in range(B)]
+    tabs = [oracle.FeatureTable(256) for _ in range(B)]
+    rng = np.random.default_rng(8)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def check(tag):
+        ids, xy, age, n, _ = ctx.batch_download()
+        for b in range(B):
+            assert _tables(ids, xy, age, n, b) == tabs[b].as_dict(), "%s stream %d" % (tag, b)
+        return ids, xy, age, n
+
+    order = [0, 1, 2, 2, 3, 4, 5, 6, 7, 8]          # frame 2 twice: identical images, zero flow
+    for k, t in enumerate(order):
+        detect = k not in (5, 6)                    # two track-only steps
+        if k == 7:                                  # forget the previous frame: the next call only stores
+            ctx.reset_tracker()
+            trks = [oracle.Tracker(*trk_args, oracle.ACC_EXACT) for _ in range(B)]
+        if detect:
+            ctx.batch_step(dev[t].data_ptr(), h * w, w, st)
+        else:
+            ctx.batch_track(dev[t].data_ptr(), h * w, w, st)
+        for b in range(B):
+            trks[b].track(tabs[b], frames[t, b])
+            if detect:
+                dets[b].update_detection(tabs[b], frames[t, b])
+        ids, xy, age, n = check("step %d" % k)
+        if k in (3, 8):                             # the host rewrites the tables: move some, drop some, reverse the order
+            for b in range(B):
+                m = int(n[b])
+                keep = np.sort(rng.choice(m, size=max(1, m - 7), replace=False))[::-1]
+                nid, nxy, nag = ids[b, keep].copy(), xy[b, keep].copy(), age[b, keep].copy()
+                moved = rng.random(len(keep)) < 0.3
+                nxy[moved] += rng.uniform(-0.75, 0.75, (int(moved.sum()), 2))
+                ids[b, :len(keep)], xy[b, :len(keep)], age[b, :len(keep)] = nid, nxy, nag
+                n[b] = len(keep)
+                tabs[b].set(nid, nxy, nag)
+            ctx.batch_upload(ids, xy, age, n)
+    assert (ctx.batch_status() == 0).all()
+    ctx.close()

@@ -66,6 +66,9 @@ struct vsf_ctx {
   float2* d_fwd = nullptr;
   uint8_t* d_flags = nullptr;
   int* d_stats = nullptr;
+  int* d_tslot = nullptr;      // [B][cap] LK template cache slot of each table entry
+  LkCacheBuf lkc[2] = {};      // LK template cache, ping-pong with the pyramids (tpl == nullptr: disabled)
+  int epoch = 0;               // bumped by every Track call
   int* d_status = nullptr;
   uint64_t* d_maxidx = nullptr;
   // detector
@@ -265,7 +268,7 @@ int build_pyramid(vsf_ctx* c, const FrameRef& f, PyrSet& ps, int streams, hipStr
   return VSF_OK;
 }
 
-int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hipStream_t s) {
+int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hipStream_t s, const LkCache& cache) {
   ProfScope prof(c, VSF_K_LK, s);
   // workgroups per stream: the table size a detector maintains (+ slack), not the (larger) capacity
   int fgrid = c->p.max_features + 64;
@@ -273,7 +276,7 @@ int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hi
   dim3 grid((unsigned)(8 * fgrid * ((streams + 7) / 8)));  // 8 XCD residue classes x streams x features
 #define VSF_LAUNCH_W(SEG)                                                                                       \
   hipLaunchKernelGGL(lk_fb_kernel<SEG>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, fgrid, \
-                     streams, c->lk, c->d_fwd, c->d_flags)
+                     streams, c->lk, c->d_fwd, c->d_flags, cache)
   switch (lk_seg_template(c->lk.seglen)) {
     case 7: VSF_LAUNCH_W(7); break;
     case 8: VSF_LAUNCH_W(8); break;
@@ -287,7 +290,7 @@ int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hi
 int launch_compact(vsf_ctx* c, int streams, hipStream_t s) {
   ProfScope prof(c, VSF_K_COMPACT, s);
   hipLaunchKernelGGL(compact_kernel, dim3(streams), dim3(256), 0, s, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap,
-                     c->d_fwd, c->d_flags, c->d_stats);
+                     c->d_fwd, c->d_flags, c->d_stats, c->d_tslot);
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
 }
@@ -386,10 +389,25 @@ int track_impl(vsf_ctx* c, const FrameRef& f, int streams, hipStream_t s) {
   int rc = build_pyramid(c, f, c->track_pyr[nxt], streams, s);
   if (rc) return rc;
   c->track_frame[nxt] = f;
+  const int rd_epoch = c->epoch;
+  c->epoch += 1;  // every Track call: entries written before a store-only call or a reset can never match again
   if (c->has_prev) {  // ref: FeatureTrackerLucasKanade.cpp:29-32 -- first call only stores the frame
     const PyrView P = make_view(c, c->track_frame[c->cur], c->track_pyr[c->cur]);
     const PyrView C = make_view(c, f, c->track_pyr[nxt]);
-    rc = launch_lk_fb(c, P, C, streams, s);
+    // template cache: read what the previous call's backward pass left for the image that is now "previous",
+    // write this call's into the other buffer (whole batch only: the buffers are indexed by stream)
+    LkCache cache;
+    memset(&cache, 0, sizeof(cache));
+    if (c->lkc[0].tpl && streams == c->B) {
+      cache.rd = c->lkc[c->cur];
+      cache.wr = c->lkc[nxt];
+      cache.tslot = c->d_tslot;
+      cache.rd_epoch = rd_epoch;
+      cache.wr_epoch = c->epoch;
+      cache.levels = c->nlevels;
+      cache.enabled = 1;
+    }
+    rc = launch_lk_fb(c, P, C, streams, s, cache);
     if (rc) return rc;
     rc = launch_compact(c, streams, s);
     if (rc) return rc;
@@ -444,7 +462,8 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
     const int sel_cap = c->grid_max > 0 ? c->grid_max : 1;
     const size_t sm = (size_t)(c->ncell + 1 + c->ncell * sel_cap) * sizeof(int);
     hipLaunchKernelGGL(append_kernel, dim3(streams), dim3(256), sm, s, G, c->d_nact, c->d_selxy, c->d_selcnt,
-                       sel_cap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, c->d_maxidx, (uint64_t)0, c->d_status);
+                       sel_cap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, c->d_maxidx, (uint64_t)0, c->d_status,
+                       c->d_tslot);
   }
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
@@ -508,7 +527,8 @@ int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long l
     ProfScope prof(c, VSF_K_APPEND, s);
     const size_t sm = (size_t)(2 + ap.kcap) * sizeof(int);
     hipLaunchKernelGGL(append_kernel, dim3(streams), dim3(256), sm, s, G, c->d_anact, c->d_aselxy, c->d_aselcnt,
-                       ap.kcap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, c->d_maxidx, (uint64_t)1, c->d_status);
+                       ap.kcap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, c->d_maxidx, (uint64_t)1, c->d_status,
+                       c->d_tslot);
   }
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
@@ -589,7 +609,7 @@ int upload_table0(vsf_ctx* c, const uint64_t* ids, const double* xy, const uint3
   // three ranges of the pack hold data; below ~64 KB one copy of the whole block is cheaper than three
   HIPCHK(c, hipMemcpyAsync(c->d_pack, hp, table_pack_bytes(c->cap), hipMemcpyHostToDevice, nullptr));
   hipLaunchKernelGGL(table_unpack_kernel, dim3((n + 255) / 256 > 0 ? (n + 255) / 256 : 1), dim3(256), 0, nullptr, c->d_pack,
-                     c->cap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->d_status);
+                     c->cap, c->d_ids, c->d_xy, c->d_age, c->d_n, c->d_status, c->d_tslot);
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
 }
@@ -712,6 +732,12 @@ void vsf_destroy(vsf_ctx* c) {
   }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->d_pack) (void)hipFree(c->d_pack);
+  if (c->d_tslot) (void)hipFree(c->d_tslot);
+  for (int i = 0; i < 2; i++) {
+    if (c->lkc[i].tpl) (void)hipFree(c->lkc[i].tpl);
+    if (c->lkc[i].hdr) (void)hipFree(c->lkc[i].hdr);
+    if (c->lkc[i].tag) (void)hipFree(c->lkc[i].tag);
+  }
   void* lssd_bufs[] = {c->d_lssd_ids, c->d_lssd_xy, c->d_lssd_n};
   for (void* b : lssd_bufs)
     if (b) (void)hipFree(b);
@@ -904,6 +930,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   A(dalloc(c, &c->d_fwd, T));
   A(dalloc(c, &c->d_flags, T));
   A(dalloc(c, &c->d_stats, (size_t)B * 4));
+  A(dalloc(c, &c->d_tslot, T));
   A(dalloc(c, &c->d_status, (size_t)B));
   A(dalloc(c, &c->d_maxidx, (size_t)B));
   A(dalloc(c, &c->d_rects, (size_t)c->ncell));
@@ -939,6 +966,30 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     A(dalloc(c, &c->d_aselcnt, (size_t)B));
   }
 #undef A
+  // LK template cache (vsf_lk.hpp): 2 x streams x capacity x levels x 2.5 KB.  Optional: a context that cannot
+  // have it (other tracker, windows above 21, more than 16 GiB, allocation failure) just recomputes templates.
+  if (!rc && !use_lssd && lk_seg_template(c->lk.seglen) <= 8) {
+    const size_t slots = (size_t)B * c->cap;
+    const size_t tpl_b = slots * c->nlevels * LK_TPL_U4 * sizeof(uint4), hdr_b = slots * c->nlevels * sizeof(float4),
+                 tag_b = slots * sizeof(float4);
+    if (2 * (tpl_b + hdr_b + tag_b) <= ((size_t)16 << 30)) {
+      bool ok = true;
+      for (int i = 0; i < 2 && ok; i++) {
+        ok = hipMalloc((void**)&c->lkc[i].tpl, tpl_b) == hipSuccess && hipMalloc((void**)&c->lkc[i].hdr, hdr_b) == hipSuccess &&
+             hipMalloc((void**)&c->lkc[i].tag, tag_b) == hipSuccess && hipMemset(c->lkc[i].tag, 0, tag_b) == hipSuccess;
+      }
+      if (!ok) {
+        (void)hipGetLastError();
+        for (int i = 0; i < 2; i++) {
+          if (c->lkc[i].tpl) (void)hipFree(c->lkc[i].tpl);
+          if (c->lkc[i].hdr) (void)hipFree(c->lkc[i].hdr);
+          if (c->lkc[i].tag) (void)hipFree(c->lkc[i].tag);
+          c->lkc[i] = LkCacheBuf{};
+        }
+      }
+    }
+  }
+  c->epoch = 1;
   if (!rc) {
     hipError_t e = hipSuccess;
     auto acc = [&](hipError_t x) {
@@ -949,6 +1000,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     acc(hipMemset(c->d_status, 0, (size_t)B * 4));
     acc(hipMemset(c->d_maxidx, 0, (size_t)B * 8));  // ref ctor: max_feature_index_(0)
     acc(hipMemset(c->d_flags, 0, T));
+    acc(hipMemset(c->d_tslot, 0xff, T * 4));
     acc(hipMemcpy(c->d_rects, rects.data(), rects.size() * sizeof(int4), hipMemcpyHostToDevice));
     acc(hipMemcpy(c->d_origin, origin.data(), origin.size() * sizeof(float2), hipMemcpyHostToDevice));
     acc(hipMemcpy(c->d_lam_off, lam_off.data(), lam_off.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -1053,7 +1105,9 @@ int vsf_track_pair(vsf_ctx* c, const uint8_t* prev, int32_t prev_stride, const u
   const FrameRef fp = own_ref(c, c->pair_frame[0]), fc = own_ref(c, c->pair_frame[1]);
   rc = build_pyramid(c, fp, c->pair_pyr[0], 1, nullptr);
   if (!rc) rc = build_pyramid(c, fc, c->pair_pyr[1], 1, nullptr);
-  if (!rc) rc = launch_lk_fb(c, make_view(c, fp, c->pair_pyr[0]), make_view(c, fc, c->pair_pyr[1]), 1, nullptr);
+  LkCache nocache;  // the stateless pair form has no previous call
+  memset(&nocache, 0, sizeof(nocache));
+  if (!rc) rc = launch_lk_fb(c, make_view(c, fp, c->pair_pyr[0]), make_view(c, fc, c->pair_pyr[1]), 1, nullptr, nocache);
   if (!rc) rc = launch_compact(c, 1, nullptr);
   if (!rc) rc = download_table0_async(c);
   if (rc) return rc;
@@ -1156,6 +1210,7 @@ int vsf_batch_upload(vsf_ctx* c, int32_t first, int32_t count, const uint64_t* i
   HIPCHK(c, hipMemcpy(c->d_xy + o, xy, T * 16, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_age + o, age, T * 4, hipMemcpyHostToDevice));
   HIPCHK(c, hipMemcpy(c->d_n + first, n, (size_t)count * 4, hipMemcpyHostToDevice));
+  HIPCHK(c, hipMemset(c->d_tslot + o, 0xff, T * 4));  // a table from the host: no cached templates
   return VSF_OK;
 }
 

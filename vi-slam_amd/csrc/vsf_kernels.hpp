@@ -17,7 +17,7 @@
 #include <type_traits>
 
 #ifndef VSF_LK_WAVES
-#define VSF_LK_WAVES 7  // waves per SIMD the LK kernels are register-limited to (window <= 21): 72 registers
+#define VSF_LK_WAVES 5  // launch bound of the LK kernels (window <= 21): the compiler settles at 80 registers, no spills, 6 waves per SIMD
 #endif
 #ifndef VSF_SUM_LDS
 #define VSF_SUM_LDS 1  // exact sums through the LDS atomic unit (0: DPP + v_readlane only)
@@ -215,7 +215,8 @@ namespace vsf {
 __global__ __launch_bounds__(256) void compact_kernel(uint64_t* __restrict__ ids, double2* __restrict__ xy,
                                                       uint32_t* __restrict__ age, int* __restrict__ n, int cap,
                                                       const float2* __restrict__ fwd,
-                                                      const uint8_t* __restrict__ flags, int* __restrict__ stats) {
+                                                      const uint8_t* __restrict__ flags, int* __restrict__ stats,
+                                                      int* __restrict__ tslot) {
   __shared__ int s_wave[4];
   __shared__ int s_base;
   __shared__ int s_cnt[3];
@@ -257,6 +258,7 @@ __global__ __launch_bounds__(256) void compact_kernel(uint64_t* __restrict__ ids
       ids[o + off] = id;
       age[o + off] = ag;
       xy[o + off] = make_double2((double)q.x, (double)q.y);  // :231-232 float -> double
+      tslot[o + off] = i;  // where the tracker kernel left this feature's template (LK template cache)
     }
     __syncthreads();
     if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
@@ -834,7 +836,8 @@ __global__ __launch_bounds__(256) void append_kernel(GridView G, const int* __re
                                                      uint64_t* __restrict__ ids, double2* __restrict__ xy,
                                                      uint32_t* __restrict__ age, int* __restrict__ n, int cap,
                                                      uint64_t* __restrict__ max_feature_index,
-                                                     uint64_t id_bias, int* __restrict__ status) {
+                                                     uint64_t id_bias, int* __restrict__ status,
+                                                     int* __restrict__ tslot) {
   extern __shared__ __align__(16) uint8_t smem[];
   int* s_off = reinterpret_cast<int*>(smem);       // [ncell+1] prefix of selected counts
   int* s_slot = s_off + (G.ncell + 1);             // [K] slot of each new feature (-1 = append)
@@ -891,6 +894,7 @@ __global__ __launch_bounds__(256) void append_kernel(GridView G, const int* __re
       ids[o + slot] = start + (uint64_t)k;
       xy[o + slot] = sel_xy[((long long)stream * G.ncell + c) * sel_cap + (k - s_off[c])];
       age[o + slot] = 1u;
+      tslot[o + slot] = -1;  // new (or overwritten) position: no cached template
     }
   }
   __syncthreads();
@@ -1009,7 +1013,7 @@ __host__ __device__ inline size_t table_pack_bytes(int cap) { return 64 + (size_
 __global__ __launch_bounds__(256) void table_unpack_kernel(const uint8_t* __restrict__ pack, int cap,
                                                            uint64_t* __restrict__ ids, double2* __restrict__ xy,
                                                            uint32_t* __restrict__ age, int* __restrict__ n,
-                                                           int* __restrict__ status) {
+                                                           int* __restrict__ status, int* __restrict__ tslot) {
   const int* hdr = reinterpret_cast<const int*>(pack);
   const double2* pxy = reinterpret_cast<const double2*>(pack + 64);
   const uint64_t* pid = reinterpret_cast<const uint64_t*>(pack + 64 + (size_t)cap * 16);
@@ -1019,6 +1023,7 @@ __global__ __launch_bounds__(256) void table_unpack_kernel(const uint8_t* __rest
     xy[i] = pxy[i];
     ids[i] = pid[i];
     age[i] = pag[i];
+    tslot[i] = -1;  // a table from the host: no cached template
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     n[0] = m;

@@ -2,6 +2,10 @@
 // Included by vsf_kernels.hpp after the common declarations (PyrView, LkParams, reflect101).
 #pragma once
 
+#ifndef VSF_LK_PREFETCH_J
+#define VSF_LK_PREFETCH_J 0
+#endif
+
 namespace vsf {
 
 // ------------------------------------------------------------------------------------------------
@@ -774,13 +778,46 @@ __device__ __forceinline__ bool lk_converged(float dx, float dy, const LkParams&
   return (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2;
 }
 
+// ---- template cache -------------------------------------------------------------------------------------
+// The backward pass of step t builds, for every surviving feature, the template of the CURRENT image at the tracked
+// position q; the forward pass of step t+1 needs the template of the same image (now the previous one) at the same
+// float position -- two thirds of the kernel's vector instructions are template set-up, and the HBM pipe idles
+// while it issues them.  So the backward pass stores what a level set-up produces (pair-packed gradients, the
+// lane's share of sum I*Ix / I*Iy, A11 / A12 / A22, the range flag: 2.5 KB per level) and the next step's forward
+// pass loads it instead of recomputing it.  A hit needs the same float position, the slot the feature had when the
+// entry was written (tslot, carried through compaction) and the epoch of the call that wrote it; anything else
+// (new features, host-uploaded tables, a reset tracker, the stateless pair form) recomputes.  The values are the ones
+// the set-up would compute from the same image and position, so results are bit-identical with or without it.
+// Two buffers ping-pong with the pyramids (a launch reads one and writes the other).
+constexpr int LK_TPL_U4 = 160;  // uint4 per (slot, level): IxP [64], IyP [64], (cI1, cI2) as 32 uint4 = 64 uint2
+
+struct LkCacheBuf {
+  uint4* tpl;   // [streams][cap][levels][LK_TPL_U4]
+  float4* hdr;  // [streams][cap][levels]  {flags (bit0 in range) as int bits, A11, A12, A22}
+  float4* tag;  // [streams][cap]          {qx, qy, epoch as int bits, 0}
+};
+struct LkCache {
+  LkCacheBuf rd, wr;
+  const int* tslot;  // [streams][cap] slot of each table entry in `rd` (-1 = none)
+  int rd_epoch, wr_epoch;
+  int levels;        // entries per slot
+  int enabled;
+};
+// this feature's entries (level 0 first); null = miss / do not write
+struct LkTplRef {
+  const uint4* rd_tpl;
+  const float4* rd_hdr;
+  uint4* wr_tpl;
+  float4* wr_hdr;
+};
+
 // Tracks one point from pyramid A (template, derivatives) to pyramid B.  One wave, wave-uniform control flow.
 // Returns the OpenCV status (true = found); out = nextPts.
 // SEG = compile-time pixels per lane (>= prm.seglen).
 template <int SEG>
 __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, float ptx, float pty,
                                float& outx, float& outy, const LkParams& prm, uint8_t* smem,
-                               const LkSmem& L) {
+                               const LkSmem& L, const LkTplRef tc = LkTplRef{nullptr, nullptr, nullptr, nullptr}) {
   constexpr int NP = (SEG + 1) / 2;         // pixel pairs per lane
   constexpr int NRAW = (SEG <= 8) ? 3 : 2;  // raw DPP steps of the exact sums (see wave_sums_exact_lds)
   const int win = prm.win;
@@ -820,8 +857,9 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     const int ipy = __builtin_amdgcn_readfirstlane((int)fpy);
     const int aw = A.w[level], ah = A.h[level];
     const bool in_range = !(ipx < -win || ipx >= aw || ipy < -win || ipy >= ah);
+    const bool cached = (SEG <= 8) && tc.rd_hdr != nullptr;  // wave-uniform
 
-    if (in_range) lk_stage_i<SEG>(A, level, stream, ipx, ipy, sI, L, lane);
+    if (in_range && !cached) lk_stage_i<SEG>(A, level, stream, ipx, ipy, sI, L, lane);
     lk_wave_sync();
     if (in_range) VSF_LKSTAT(level * 16 + 0);
 
@@ -829,11 +867,49 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     const int bp = B.pitch[level], bw = B.w[level], bh = B.h[level];
     bool level_ok = in_range;
     if (!in_range && level == 0) status = false;
+#if VSF_LK_PREFETCH_J
+    // The first J region of the level is known before the template exists (it depends on nextPt only): issue its
+    // loads now, so that their latency runs under the template work instead of in front of the first iteration.
+    constexpr int NJP = (SEG <= 8) ? 4 : 10;
+    unsigned int rjp[NJP];
+    int pjx0 = 0, pjy0 = 0;
+    bool pre = false;
+    if (in_range) {
+      const int pinx = __builtin_amdgcn_readfirstlane((int)floorf(nx - half));
+      const int piny = __builtin_amdgcn_readfirstlane((int)floorf(ny - half));
+      pjx0 = (pinx - prm.jmargin) & ~3;
+      pjy0 = piny - prm.jmargin;
+      if (!(pinx < -win || pinx >= bw || piny < -win || piny >= bh) && region_is_fast(Bb, bp, bw, bh, pjx0, pjy0, L.gj)) {
+        region_load_regs<NJP>(rjp, Bb, bp, pjx0, pjy0, L.gj, lane);
+        pre = true;
+      }
+    }
+#endif
 
     unsigned int IxP[NP], IyP[NP];  // template gradients, pair-packed, zero where the lane owns no pixel
     int cI1 = 0, cI2 = 0;
     float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
-    if (level_ok) {
+    if (level_ok && cached) {
+      VSF_LKSTAT(level * 16 + 9);
+      if constexpr (SEG <= 8) {
+        // the entry the previous step's backward pass left for this image and position
+        const float4 h = tc.rd_hdr[level];
+        const uint4* t = tc.rd_tpl + level * LK_TPL_U4;
+        const uint4 gx = t[lane], gy = t[64 + lane];
+        const uint2 ci = reinterpret_cast<const uint2*>(t + 128)[lane];
+        IxP[0] = gx.x, IxP[1] = gx.y, IxP[2] = gx.z, IxP[3] = gx.w;
+        IyP[0] = gy.x, IyP[1] = gy.y, IyP[2] = gy.z, IyP[3] = gy.w;
+        cI1 = (int)ci.x;
+        cI2 = (int)ci.y;
+        A11 = h.y;
+        A12 = h.z;
+        A22 = h.w;
+        if (lk_reject_level(A11, A12, A22, D, prm)) {
+          if (level == 0) status = false;
+          level_ok = false;
+        }
+      }
+    } else if (level_ok) {
       const float fa = px - fpx, fb = py - fpy;
       int iw00, iw01, iw10, iw11;
       bilinear_weights_uniform(fa, fb, iw00, iw01, iw10, iw11);
@@ -851,10 +927,23 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       A11 = Asum[0] * FLT_SCALE;
       A12 = Asum[1] * FLT_SCALE;
       A22 = Asum[2] * FLT_SCALE;
+      if constexpr (SEG <= 8) {
+        if (tc.wr_hdr != nullptr) {  // leave the template for the next step's forward pass (fire and forget)
+          uint4* t = tc.wr_tpl + level * LK_TPL_U4;
+          t[lane] = make_uint4(IxP[0], IxP[1], IxP[2], IxP[3]);
+          t[64 + lane] = make_uint4(IyP[0], IyP[1], IyP[2], IyP[3]);
+          reinterpret_cast<uint2*>(t + 128)[lane] = make_uint2((unsigned int)cI1, (unsigned int)cI2);
+          if (lane == 0) tc.wr_hdr[level] = make_float4(__int_as_float(1), A11, A12, A22);
+        }
+      }
       if (lk_reject_level(A11, A12, A22, D, prm)) {
         if (level == 0) status = false;
         level_ok = false;
       }
+    }
+    if constexpr (SEG <= 8) {
+      // a level out of range leaves an entry too: the reader takes the same path from its own range test
+      if (!in_range && tc.wr_hdr != nullptr && lane == 0) tc.wr_hdr[level] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
     if (level_ok) {
@@ -879,7 +968,15 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           lk_wave_sync();  // previous iteration's reads are done
           jx0 = (inx - prm.jmargin) & ~3;
           jy0 = iny - prm.jmargin;
-          lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
+#if VSF_LK_PREFETCH_J
+          if (pre && jx0 == pjx0 && jy0 == pjy0)
+            region_store_pairs<NJP>(sJ, rjp, L.gj, L.jp_pitch, lane);
+          else
+#endif
+            lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
+#if VSF_LK_PREFETCH_J
+          pre = false;
+#endif
           staged = true;
           VSF_LKSTAT(level * 16 + 3);
           lk_wave_sync();
@@ -972,7 +1069,7 @@ template <int SEG>
 __global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
                                                    const int* __restrict__ n, int cap, int fgrid, int nstreams,
                                                    LkParams prm, float2* __restrict__ fwd,
-                                                   uint8_t* __restrict__ flags) {
+                                                   uint8_t* __restrict__ flags, LkCache cache) {
   extern __shared__ __align__(16) uint8_t smem[];
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so all
   // features of one stream are given to ONE residue class: their overlapping window lines are then
@@ -987,23 +1084,41 @@ __global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_fb_kerne
   if (f0 >= nf) return;
   const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
   lk_init_masks<SEG>(prm, smem, L);
+  const long long so = (long long)stream * cap;
   for (int f = f0; f < nf; f += fgrid) {
-    const double2 p0 = xy[(long long)stream * cap + f];
+    const double2 p0 = xy[so + f];
     const float p0x = (float)p0.x, p0y = (float)p0.y;  // :210 double -> float narrowing
+    LkTplRef fw = {nullptr, nullptr, nullptr, nullptr}, bw = {nullptr, nullptr, nullptr, nullptr};
+    if (SEG <= 8 && cache.enabled) {
+      const int sl = cache.tslot[so + f];
+      if (sl >= 0 && sl < cap) {
+        const float4 tg = cache.rd.tag[so + sl];
+        if (__float_as_int(tg.z) == cache.rd_epoch && __float_as_int(tg.x) == __float_as_int(p0x) &&
+            __float_as_int(tg.y) == __float_as_int(p0y)) {
+          fw.rd_tpl = cache.rd.tpl + (so + sl) * cache.levels * LK_TPL_U4;
+          fw.rd_hdr = cache.rd.hdr + (so + sl) * cache.levels;
+        }
+      }
+      bw.wr_tpl = cache.wr.tpl + (so + f) * cache.levels * LK_TPL_U4;
+      bw.wr_hdr = cache.wr.hdr + (so + f) * cache.levels;
+    }
     float qx, qy;
     uint8_t flag = 0;
-    if (lk_track_point<SEG>(P, C, stream, p0x, p0y, qx, qy, prm, smem, L)) {
+    if (lk_track_point<SEG>(P, C, stream, p0x, p0y, qx, qy, prm, smem, L, fw)) {
       flag |= 1;
       float rx, ry;
-      if (lk_track_point<SEG>(C, P, stream, qx, qy, rx, ry, prm, smem, L)) {
+      if (lk_track_point<SEG>(C, P, stream, qx, qy, rx, ry, prm, smem, L, bw)) {
         flag |= 2;
         const double ddx = (double)rx - p0.x, ddy = (double)ry - p0.y;
         if (sqrt(ddx * ddx + ddy * ddy) <= prm.backtrack_thr) flag |= 4;
       }
     }
     if ((threadIdx.x & 63) == 0) {
-      fwd[(long long)stream * cap + f] = make_float2(qx, qy);
-      flags[(long long)stream * cap + f] = flag;
+      fwd[so + f] = make_float2(qx, qy);
+      flags[so + f] = flag;
+      // the slot is valid for the position the backward pass started from, in the image that is "previous" next time
+      if (SEG <= 8 && cache.enabled && (flag & 1))
+        cache.wr.tag[so + f] = make_float4(qx, qy, __int_as_float(cache.wr_epoch), 0.f);
     }
   }
 }
