@@ -370,8 +370,10 @@ constexpr int SC_IP = 80;  // LDS pitch of the staged 8-bit tile (tile width + u
 constexpr int SC_LP = SC_TW + 1;               // LDS pitch of the lambda block
 constexpr int SC_LCAP = SC_IH * SC_IW / 4 + 64;  // keys gathered in LDS per block; beyond it they go straight to the list
 
-__host__ __device__ inline int sc_tiles(int cells_extent, int step) {  // tiles covering positions -1 .. extent
-  const int t = (cells_extent - 1 + step - 1) / step;
+// Tiles along one axis of a cell: tile t holds lambda at [t * step, t * step + step + 2) and candidates one in
+// from both ends, so T tiles cover the candidates 1 .. T * step and lambda 0 .. T * step + 1.
+__host__ __device__ inline int sc_tiles(int cells_extent, int step) {
+  const int t = (cells_extent - 2 + step - 1) / step;
   return t > 1 ? t : 1;
 }
 
@@ -403,8 +405,12 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   __shared__ unsigned int s_max;
   __shared__ int s_n, s_base;
   const int cw = rc.z, ch = rc.w;
-  const int cx0 = tx * SC_IW - 1, cy0 = ty * SC_IH - 1;  // origin of the lambda block in cell coordinates
-  if (cx0 + 1 >= cw || cy0 + 1 >= ch) return;            // block-uniform: the tile lies outside this cell
+  const int cx0 = tx * SC_IW, cy0 = ty * SC_IH;  // origin of the lambda block in cell coordinates
+  if (tx >= sc_tiles(cw, SC_IW) || ty >= sc_tiles(ch, SC_IH)) return;  // block-uniform: a smaller cell needs fewer tiles
+  // cv::boxFilter reflects (REFLECT_101) at the CELL border.  Unless the cell is tiny, the covariance stage stores
+  // every product it forms one or two rows / columns inside the border a second time at its mirror position outside,
+  // and the box stage of border tiles then runs the same straight-line code as that of inner tiles.
+  const bool mirror = cw >= 4 && ch >= 4;
   unsigned int seen = 0u;
   if (EMIT) seen = __hip_atomic_load(cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) {
@@ -458,28 +464,47 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
         sv += k_side * f2;
         ss = sv;
       };
-      float r0, s0, r1, s1;
-      rowvals(y0, r0, s0);
-      rowvals(y0 + 1, r1, s1);
       const int cx = cx0 - HL + x;
-      const bool xin = cx >= 0 && cx < cw;
+      const bool xin = mirror ? (cx >= -HL && cx < cw + HR) : (cx >= 0 && cx < cw);
+      // a column outside the cell carries its mirror's products: it reads the mirror's image columns
+      if (mirror && xin) col += reflect101(cx, cw) - cx;
+      auto put = [&](int yy, float pxx, float pxy, float pyy) {
+        s_cov[0][yy * CW + x] = pxx;
+        s_cov[1][yy * CW + x] = pxy;
+        s_cov[2][yy * CW + x] = pyy;
+      };
+      if (xin || !mirror) {
+        float r0, s0, r1, s1;
+        rowvals(y0, r0, s0);
+        rowvals(y0 + 1, r1, s1);
 #pragma unroll
-      for (int k = 0; k < RS; k++) {
-        const int y = y0 + k;
-        if (y < CH) {
-          float r2, s2;
-          rowvals(y + 2, r2, s2);
-          const float dx = (r0 + r2) * k_side + r1 * k_mid;
-          const float dy = s2 - s0;
-          const int cy = cy0 - HL + y;
-          const bool in = xin && cy >= 0 && cy < ch;
-          s_cov[0][y * CW + x] = in ? dx * dx : 0.f;
-          s_cov[1][y * CW + x] = in ? dx * dy : 0.f;
-          s_cov[2][y * CW + x] = in ? dy * dy : 0.f;
-          r0 = r1;
-          s0 = s1;
-          r1 = r2;
-          s1 = s2;
+        for (int k = 0; k < RS; k++) {
+          const int y = y0 + k;
+          if (y < CH) {
+            float r2, s2;
+            rowvals(y + 2, r2, s2);
+            const float dx = (r0 + r2) * k_side + r1 * k_mid;
+            const float dy = s2 - s0;
+            const int cy = cy0 - HL + y;
+            const bool in = xin && cy >= 0 && cy < ch;
+            if (!mirror) {
+              put(y, in ? dx * dx : 0.f, in ? dx * dy : 0.f, in ? dy * dy : 0.f);
+            } else if (in) {
+              const float pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
+              put(y, pxx, pxy, pyy);
+              // rows -d and ch - 1 + d mirror rows d and ch - 1 - d (their own walkers store nothing)
+#pragma unroll
+              for (int d = 1; d <= HL; d++)
+                if (cy == d && y - 2 * d >= 0) put(y - 2 * d, pxx, pxy, pyy);
+#pragma unroll
+              for (int d = 1; d <= HR; d++)
+                if (cy == ch - 1 - d && y + 2 * d < CH) put(y + 2 * d, pxx, pxy, pyy);
+            }
+            r0 = r1;
+            s0 = s1;
+            r1 = r2;
+            s1 = s2;
+          }
         }
       }
     }
@@ -508,34 +533,35 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   };
   // Box filter in double like cv::boxFilter for 32F input: row sum left to right, then the column of
   // row sums top to bottom.
-  const bool box_interior = cx0 - HL >= 0 && cx0 + SC_TW + HR <= cw && cy0 - HL >= 0 && cy0 + SC_TH + HR <= ch;
-  if (box_interior) {
-    // no reflection inside the tile: a thread owns one column and four consecutive rows, forms the
-    // BS + 3 row sums they share once, and adds BS of them per pixel (same additions, same order)
+  if (mirror) {
+    // a thread owns one column and four consecutive rows, forms the BS + 3 row sums they share once, and adds BS
+    // of them per pixel (same additions, same order); positions outside the cell are skipped
     const int x = threadIdx.x & (SC_TW - 1), y0 = (threadIdx.x / SC_TW) * 4;
     static_assert(SC_TH == 16 && SC_TW * 4 == 256, "strip mapping");
-    double rs[3][BS + 3];
+    if (cx0 + x < cw && cy0 + y0 < ch) {
+      double rs[3][BS + 3];
 #pragma unroll
-    for (int k = 0; k < BS + 3; k++) {
+      for (int k = 0; k < BS + 3; k++) {
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const float* row = s_cov[q] + (y0 + k) * CW + x;
-        double t = (double)row[0];
+        for (int q = 0; q < 3; q++) {
+          const float* row = s_cov[q] + (y0 + k) * CW + x;
+          double t = (double)row[0];
 #pragma unroll
-        for (int i = 1; i < BS; i++) t += (double)row[i];
-        rs[q][k] = t;
+          for (int i = 1; i < BS; i++) t += (double)row[i];
+          rs[q][k] = t;
+        }
       }
-    }
 #pragma unroll
-    for (int o = 0; o < 4; o++) {
-      double sum[3];
+      for (int o = 0; o < 4; o++) {
+        double sum[3];
 #pragma unroll
-      for (int q = 0; q < 3; q++) {
-        sum[q] = rs[q][o];
+        for (int q = 0; q < 3; q++) {
+          sum[q] = rs[q][o];
 #pragma unroll
-        for (int j = 1; j < BS; j++) sum[q] += rs[q][o + j];
+          for (int j = 1; j < BS; j++) sum[q] += rs[q][o + j];
+        }
+        if (cy0 + y0 + o < ch) finish(x, y0 + o, sum);
       }
-      finish(x, y0 + o, sum);
     }
   } else {
     for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
