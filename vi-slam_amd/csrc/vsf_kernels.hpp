@@ -366,7 +366,7 @@ __device__ __forceinline__ float float_order_decode(unsigned int e) {
 //     reflects at the CELL border and sums in double like cv::boxFilter does for 32F input.
 constexpr int SC_TW = 64, SC_TH = 16;          // lambda block of a tile
 constexpr int SC_IW = SC_TW - 2, SC_IH = SC_TH - 2;  // candidate positions of a tile (tile step)
-constexpr int SC_IP = 80;  // LDS pitch of the staged 8-bit tile (tile width + up to 3 bytes of dword alignment)
+constexpr int SC_FP = 76;  // LDS pitch (floats) of the staged tile (tile width + up to 3 pixels of dword alignment)
 constexpr int SC_LP = SC_TW + 1;               // LDS pitch of the lambda block
 constexpr int SC_LCAP = SC_IH * SC_IW / 4 + 64;  // keys gathered in LDS per block; beyond it they go straight to the list
 
@@ -389,18 +389,25 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
                                            int* __restrict__ ccnt) {
   constexpr int HL = BS / 2, HR = BS - 1 - HL;             // covariance halo left/top, right/bottom
   constexpr int CW = SC_TW + HL + HR, CH = SC_TH + HL + HR;  // covariance tile
-  constexpr int IW = CW + 2, IH = CH + 2;                  // staged 8-bit tile (Sobel reads +-1 more)
-  static_assert(IW + 3 <= SC_IP && SC_IP % 4 == 0, "tile pitch");
-  // LDS: the staged image is dead once the covariances exist, and those once lambda exists; the mask bits and
-  // the gathered keys reuse their space (the kernel runs on occupancy: three barriers and dependent LDS round
-  // trips per tile, 8 blocks per CU at 20 KB each)
-  constexpr int IMG_BYTES = (IH * SC_IP + 15) & ~15, COV_BYTES = 3 * CH * CW * 4;
-  static_assert(SC_TH * SC_TW <= IMG_BYTES && SC_LCAP * 8 <= COV_BYTES, "aliased regions");
+  constexpr int IW = CW + 2, IH = CH + 2;                  // staged image tile (Sobel reads +-1 more)
+  constexpr int NDW = (IW + 3 + 3) / 4;                    // dwords of a staged row (up to 3 bytes of alignment slack)
+  static_assert(4 * NDW <= SC_FP && SC_FP % 4 == 0, "tile pitch");
+  // LDS: the staged image (as float32: every pixel is converted once, not once per use) is dead once the
+  // covariance products exist, and those once lambda exists; the lambda block and the mask bits reuse the
+  // image's space, the gathered keys the products'.  20 KB a block, 7 blocks per CU.  (The products stay
+  // float32 although the box filter sums them in double: held as float64 the conversions drop to a third,
+  // but the 8-byte LDS reads of the box stage then cost more than the conversions saved -- the LDS pipe is
+  // nearly as busy as the VALU here -- and the kernel ran 1.7x slower.)
+  constexpr int IMG_BYTES = IH * SC_FP * 4, COV_BYTES = 3 * CH * CW * 4;
+  constexpr int LAM_BYTES = (SC_TH * SC_LP * 4 + 15) & ~15;
+  static_assert(IMG_BYTES % 16 == 0 && LAM_BYTES + SC_TH * SC_TW <= IMG_BYTES && SC_LCAP * 8 <= COV_BYTES,
+                "aliased regions");
   __shared__ __align__(16) uint8_t s_raw[IMG_BYTES + COV_BYTES];
-  __shared__ float s_lam[EMIT ? SC_TH * SC_LP : 1];
-  uint8_t* s_img = s_raw;
-  uint8_t* s_msk = s_raw;                                                         // after the covariance stage
-  float(*s_cov)[CH * CW] = reinterpret_cast<float(*)[CH * CW]>(s_raw + IMG_BYTES);  // dx*dx, dx*dy, dy*dy (float32 products, as cv)
+  float* s_img = reinterpret_cast<float*>(s_raw);
+  float* s_lam = reinterpret_cast<float*>(s_raw);  // after the covariance stage
+  uint8_t* s_msk = s_raw + LAM_BYTES;              // after the covariance stage
+  // dx*dx, dx*dy, dy*dy: float32 products as cv forms them
+  float(*s_cov)[CH * CW] = reinterpret_cast<float(*)[CH * CW]>(s_raw + IMG_BYTES);
   unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw + IMG_BYTES);  // after the lambda stage
   __shared__ unsigned int s_max;
   __shared__ int s_n, s_base;
@@ -411,6 +418,8 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // every product it forms one or two rows / columns inside the border a second time at its mirror position outside,
   // and the box stage of border tiles then runs the same straight-line code as that of inner tiles.
   const bool mirror = cw >= 4 && ch >= 4;
+  // block-uniform: this tile holds a mirrored row (only the cell's first and last tile rows do)
+  const bool edge_rows = cy0 == 0 || ch - cy0 < SC_TH + HR + 1;
   unsigned int seen = 0u;
   if (EMIT) seen = __hip_atomic_load(cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) {
@@ -422,77 +431,82 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // tiles away from the image border are fetched as aligned dwords (sh = bytes of alignment slack);
   // border tiles byte by byte with REFLECT_101
   const int sh = gx0 & 3;
-  constexpr int NDW = (IW + 3 + 3) / 4;
   const bool img_interior = gx0 >= 0 && gy0 >= 0 && gx0 + IW <= w && gy0 + IH <= h && (row_stride & 3) == 0 &&
                             (reinterpret_cast<uintptr_t>(F) & 3) == 0 && (gx0 - sh) + 4 * NDW <= row_stride;
   if (img_interior) {
     const unsigned int* Fw = reinterpret_cast<const unsigned int*>(F + (long long)gy0 * row_stride + (gx0 - sh));
     const unsigned int rsw = (unsigned int)row_stride >> 2;
-    unsigned int* sw = reinterpret_cast<unsigned int*>(s_img);
     for (int i = threadIdx.x; i < IH * NDW; i += 256) {
       const int y = i / NDW, xd = i - y * NDW;
-      sw[y * (SC_IP / 4) + xd] = Fw[(unsigned int)y * rsw + (unsigned int)xd];
+      const unsigned int v = Fw[(unsigned int)y * rsw + (unsigned int)xd];
+      *reinterpret_cast<float4*>(s_img + y * SC_FP + 4 * xd) =
+          make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
     }
   } else {
     for (int i = threadIdx.x; i < IH * IW; i += 256) {
       const int y = i / IW, x = i - y * IW;
       const int gy = reflect101(gy0 + y, h), gx = reflect101(gx0 + x, w);
-      s_img[y * SC_IP + sh + x] = F[(long long)gy * row_stride + gx];
+      s_img[y * SC_FP + sh + x] = (float)F[(long long)gy * row_stride + gx];
     }
   }
   __syncthreads();
   // covariance at cell coords [cx0-HL, cx0+SC_TW+HR) x [cy0-HL, cy0+SC_TH+HR) that lie inside the cell.
-  // A thread walks one column of the tile down a strip of RS rows: per image row it forms the horizontal
+  // A thread walks one column of the tile down a strip of rows: per image row it forms the horizontal
   // difference r = I(x+1) - I(x-1) and the horizontal smooth s = k I(x-1) + 2k I(x) + k I(x+1) ONCE, and every
   // covariance row combines three consecutive (r, s) pairs -- the same float operations in the same order as
-  // the direct 3x3 form, a third of the conversions and multiplies.
+  // the direct 3x3 form, a third of the multiplies.  Waves 0..2 take columns 0..63 in three strips of RS rows;
+  // the two or three columns left over go to wave 3, one (column, row) per lane (spread over the 198 or 201
+  // threads of a plain column-major split, the fourth wave would run the whole strip for half a dozen lanes).
   {
     constexpr int RS = (CH + 2) / 3;
-    static_assert(3 * CW <= 256 && 3 * RS >= CH, "strip mapping of the covariance stage");
-    const int t = threadIdx.x;
-    const int strip = (t >= CW ? 1 : 0) + (t >= 2 * CW ? 1 : 0);
-    const int x = t - strip * CW;
-    if (t < 3 * CW) {
-      const int y0 = strip * RS;
-      const uint8_t* col = s_img + (sh + x);
-      auto rowvals = [&](int iy, float& rr, float& ss) {
-        const uint8_t* c = col + iy * SC_IP;
-        const float f0 = (float)c[0], f1 = (float)c[1], f2 = (float)c[2];
-        rr = f2 - f0;  // exact: equals (float)(int difference)
-        float sv = k_side * f0;
-        sv += k_mid * f1;
-        sv += k_side * f2;
-        ss = sv;
-      };
-      const int cx = cx0 - HL + x;
-      const bool xin = mirror ? (cx >= -HL && cx < cw + HR) : (cx >= 0 && cx < cw);
-      // a column outside the cell carries its mirror's products: it reads the mirror's image columns
-      if (mirror && xin) col += reflect101(cx, cw) - cx;
-      auto put = [&](int yy, float pxx, float pxy, float pyy) {
-        s_cov[0][yy * CW + x] = pxx;
-        s_cov[1][yy * CW + x] = pxy;
-        s_cov[2][yy * CW + x] = pyy;
-      };
-      if (xin || !mirror) {
-        float r0, s0, r1, s1;
-        rowvals(y0, r0, s0);
-        rowvals(y0 + 1, r1, s1);
+    static_assert(3 * RS >= CH && (CW - 64) * CH <= 64 && CW > 64, "strip mapping of the covariance stage");
+    const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
+    int x, y0, nrows;
+    if (wv < 3) {
+      x = ln, y0 = wv * RS, nrows = min(RS, CH - y0);
+    } else {
+      const int c = ln / CH;
+      x = 64 + c, y0 = ln - c * CH, nrows = (ln < (CW - 64) * CH) ? 1 : 0;
+    }
+    const int cx = cx0 - HL + x;
+    const bool xin = mirror ? (cx >= -HL && cx < cw + HR) : (cx >= 0 && cx < cw);
+    // a column outside the cell carries its mirror's products: it reads the mirror's image columns
+    const float* col = s_img + (sh + x) + ((mirror && xin) ? reflect101(cx, cw) - cx : 0);
+    auto rowvals = [&](int iy, float& rr, float& ss) {
+      const float* c = col + iy * SC_FP;
+      const float f0 = c[0], f1 = c[1], f2 = c[2];
+      rr = f2 - f0;  // exact: equals (float)(int difference)
+      float sv = k_side * f0;
+      sv += k_mid * f1;
+      sv += k_side * f2;
+      ss = sv;
+    };
+    auto put = [&](int yy, float pxx, float pxy, float pyy) {
+      s_cov[0][yy * CW + x] = pxx;
+      s_cov[1][yy * CW + x] = pxy;
+      s_cov[2][yy * CW + x] = pyy;
+    };
+    if (nrows > 0 && (xin || !mirror)) {
+      float r0, s0, r1, s1;
+      rowvals(y0, r0, s0);
+      rowvals(y0 + 1, r1, s1);
 #pragma unroll
-        for (int k = 0; k < RS; k++) {
-          const int y = y0 + k;
-          if (y < CH) {
-            float r2, s2;
-            rowvals(y + 2, r2, s2);
-            const float dx = (r0 + r2) * k_side + r1 * k_mid;
-            const float dy = s2 - s0;
-            const int cy = cy0 - HL + y;
-            const bool in = xin && cy >= 0 && cy < ch;
-            if (!mirror) {
-              put(y, in ? dx * dx : 0.f, in ? dx * dy : 0.f, in ? dy * dy : 0.f);
-            } else if (in) {
-              const float pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
-              put(y, pxx, pxy, pyy);
-              // rows -d and ch - 1 + d mirror rows d and ch - 1 - d (their own walkers store nothing)
+      for (int k = 0; k < RS; k++) {
+        const int y = y0 + k;
+        if (k < nrows) {
+          float r2, s2;
+          rowvals(y + 2, r2, s2);
+          const float dx = (r0 + r2) * k_side + r1 * k_mid;
+          const float dy = s2 - s0;
+          const int cy = cy0 - HL + y;
+          const bool in = xin && cy >= 0 && cy < ch;
+          if (!mirror) {
+            put(y, in ? dx * dx : 0.f, in ? dx * dy : 0.f, in ? dy * dy : 0.f);
+          } else if (in) {
+            const float pxx = dx * dx, pxy = dx * dy, pyy = dy * dy;
+            put(y, pxx, pxy, pyy);
+            // rows -d and ch - 1 + d mirror rows d and ch - 1 - d (their own walkers store nothing)
+            if (edge_rows) {
 #pragma unroll
               for (int d = 1; d <= HL; d++)
                 if (cy == d && y - 2 * d >= 0) put(y - 2 * d, pxx, pxy, pyy);
@@ -500,11 +514,11 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
               for (int d = 1; d <= HR; d++)
                 if (cy == ch - 1 - d && y + 2 * d < CH) put(y + 2 * d, pxx, pxy, pyy);
             }
-            r0 = r1;
-            s0 = s1;
-            r1 = r2;
-            s1 = s2;
           }
+          r0 = r1;
+          s0 = s1;
+          r1 = r2;
+          s1 = s2;
         }
       }
     }
@@ -551,6 +565,8 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
           rs[q][k] = t;
         }
       }
+      // the image tile is dead (barrier above); lambda and mask bits go where it was.  No thread reads
+      // s_lam / s_msk before the barrier after this stage.
 #pragma unroll
       for (int o = 0; o < 4; o++) {
         double sum[3];
