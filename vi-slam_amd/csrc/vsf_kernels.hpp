@@ -398,7 +398,9 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // float32 although the box filter sums them in double: held as float64 the conversions drop to a third,
   // but the 8-byte LDS reads of the box stage then cost more than the conversions saved -- the LDS pipe is
   // nearly as busy as the VALU here -- and the kernel ran 1.7x slower.)
-  constexpr int IMG_BYTES = IH * SC_FP * 4, COV_BYTES = 3 * CH * CW * 4;
+  constexpr int RS = (CH + 2) / 3;  // rows of a covariance strip; the product planes are padded to 3 * RS rows
+  constexpr int CHP = 3 * RS;       // so that the last strip needs no row test
+  constexpr int IMG_BYTES = IH * SC_FP * 4, COV_BYTES = 3 * CHP * CW * 4;
   constexpr int LAM_BYTES = (SC_TH * SC_LP * 4 + 15) & ~15;
   static_assert(IMG_BYTES % 16 == 0 && LAM_BYTES + SC_TH * SC_TW <= IMG_BYTES && SC_LCAP * 8 <= COV_BYTES,
                 "aliased regions");
@@ -407,7 +409,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   float* s_lam = reinterpret_cast<float*>(s_raw);  // after the covariance stage
   uint8_t* s_msk = s_raw + LAM_BYTES;              // after the covariance stage
   // dx*dx, dx*dy, dy*dy: float32 products as cv forms them
-  float(*s_cov)[CH * CW] = reinterpret_cast<float(*)[CH * CW]>(s_raw + IMG_BYTES);
+  float(*s_cov)[CHP * CW] = reinterpret_cast<float(*)[CHP * CW]>(s_raw + IMG_BYTES);
   unsigned long long* s_keys = reinterpret_cast<unsigned long long*>(s_raw + IMG_BYTES);  // after the lambda stage
   __shared__ unsigned int s_max;
   __shared__ int s_n, s_base;
@@ -458,7 +460,6 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // the two or three columns left over go to wave 3, one (column, row) per lane (spread over the 198 or 201
   // threads of a plain column-major split, the fourth wave would run the whole strip for half a dozen lanes).
   {
-    constexpr int RS = (CH + 2) / 3;
     static_assert(3 * RS >= CH && (CW - 64) * CH <= 64 && CW > 64, "strip mapping of the covariance stage");
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
     int x, y0, nrows;
@@ -486,7 +487,30 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
       s_cov[1][yy * CW + x] = pxy;
       s_cov[2][yy * CW + x] = pyy;
     };
-    if (nrows > 0 && (xin || !mirror)) {
+    if (wv < 3 && mirror && !edge_rows) {
+      // every row of the tile lies inside the cell: straight-line code, no per-row test the compiler would
+      // turn into a branch (as basic blocks per row the LDS reads of a row no longer overlap the arithmetic
+      // of the one before: +12 % on the whole kernel, measured).  The last strip runs past row CH - 1: it reads
+      // whatever follows the image tile in LDS and stores the result to the padding rows, which nobody reads.
+      if (xin) {
+        float r0, s0, r1, s1;
+        rowvals(y0, r0, s0);
+        rowvals(y0 + 1, r1, s1);
+#pragma unroll
+        for (int k = 0; k < RS; k++) {
+          const int y = y0 + k;
+          float r2, s2;
+          rowvals(y + 2, r2, s2);
+          const float dx = (r0 + r2) * k_side + r1 * k_mid;
+          const float dy = s2 - s0;
+          put(y, dx * dx, dx * dy, dy * dy);
+          r0 = r1;
+          s0 = s1;
+          r1 = r2;
+          s1 = s2;
+        }
+      }
+    } else if (nrows > 0 && (xin || !mirror)) {
       float r0, s0, r1, s1;
       rowvals(y0, r0, s0);
       rowvals(y0 + 1, r1, s1);
@@ -527,7 +551,10 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   unsigned int local_max = 0u;
   const float thr_seen = (EMIT && seen) ? (float)((double)float_order_decode(seen) * quality) : -INFINITY;
   // (x, y): position inside the lambda block; (cx, cy) = (cx0 + x, cy0 + y) lies inside the cell
-  auto finish = [&](int x, int y, const double (&sum)[3]) {
+  auto mask_at = [&](int cx, int cy) -> bool {
+    return !M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)];
+  };
+  auto finish = [&](int x, int y, const double (&sum)[3], bool mk) {
     const int cx = cx0 + x, cy = cy0 + y;
     const float a = (float)sum[0] * 0.5f, b = (float)sum[1], c = (float)sum[2] * 0.5f;
     // lambda <= a + c.  Where a + c is not above quality * (the cell maximum seen at block start) the pixel passes
@@ -538,7 +565,6 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
     const bool full = WRITE_LAM || a + c > thr_seen;
     if (full) lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
     if (WRITE_LAM) lam_cell[cy * cw + cx] = lm;
-    const bool mk = !M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)];
     if (EMIT) {
       s_lam[y * SC_LP + x] = lm;
       s_msk[y * SC_TW + x] = mk ? 1 : 0;
@@ -553,6 +579,11 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
     const int x = threadIdx.x & (SC_TW - 1), y0 = (threadIdx.x / SC_TW) * 4;
     static_assert(SC_TH == 16 && SC_TW * 4 == 256, "strip mapping");
     if (cx0 + x < cw && cy0 + y0 < ch) {
+      // the four mask bytes first (rows clamped into the cell), so that their global latency runs under the row
+      // sums (loaded per pixel behind the row test the kernel also needs 6 to 20 registers more)
+      bool mk4[4];
+#pragma unroll
+      for (int o = 0; o < 4; o++) mk4[o] = mask_at(cx0 + x, min(cy0 + y0 + o, ch - 1));
       double rs[3][BS + 3];
 #pragma unroll
       for (int k = 0; k < BS + 3; k++) {
@@ -576,7 +607,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
 #pragma unroll
           for (int j = 1; j < BS; j++) sum[q] += rs[q][o + j];
         }
-        if (cy0 + y0 + o < ch) finish(x, y0 + o, sum);
+        if (cy0 + y0 + o < ch) finish(x, y0 + o, sum, mk4[o]);
       }
     }
   } else {
@@ -600,7 +631,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
             sum[q] = (j == 0) ? t : sum[q] + t;
           }
         }
-        finish(x, y, sum);
+        finish(x, y, sum, mask_at(cx, cy));
       }
     }
   }
