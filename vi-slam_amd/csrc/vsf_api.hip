@@ -241,6 +241,14 @@ int alloc_pyr(vsf_ctx* c, PyrSet* ps, int streams) {
   return VSF_OK;
 }
 
+// Vertically adjacent tiles one block of pyr_down_dword_kernel walks (it prefetches the next tile while it filters
+// the current one): up to 5, fewer while that would leave the chip short of blocks.
+int pyr_tiles_y(int tiles_x, int tiles_y_total, int streams) {
+  int t = tiles_y_total < 5 ? tiles_y_total : 5;
+  while (t > 1 && (long long)tiles_x * ((tiles_y_total + t - 1) / t) * streams < 8192) t--;
+  return t;
+}
+
 // cv::buildOpticalFlowPyramid levels >= 1 (level 0 is the frame itself); lv[l] = level l of stream 0
 void launch_pyramid(const FrameRef& f, uint8_t* const* lv, int nlevels, const int* lw, const int* lh, const int* lp,
                     int streams, hipStream_t s) {
@@ -252,10 +260,11 @@ void launch_pyramid(const FrameRef& f, uint8_t* const* lv, int nlevels, const in
     const long long dst_sst = (long long)lp[l] * lh[l];
     const bool aligned = ((uintptr_t)src % 4 == 0) && sst % 4 == 0 && sp % 4 == 0 && lw[l - 1] % 4 == 0 &&
                          lw[l - 1] >= 8 && ((uintptr_t)lv[l] % 4 == 0) && dst_sst % 4 == 0 && lp[l] % 4 == 0;
-    if (aligned)
-      hipLaunchKernelGGL(pyr_down_dword_kernel<false>, grid, dim3(256), 0, s, src, sst, sp, lw[l - 1], lh[l - 1],
-                         (void*)lv[l], dst_sst, lp[l], lw[l], lh[l]);
-    else
+    if (aligned) {
+      const int ty = pyr_tiles_y(grid.x, grid.y, streams);
+      hipLaunchKernelGGL(pyr_down_dword_kernel<false>, dim3(grid.x, (grid.y + ty - 1) / ty, streams), dim3(256), 0, s, src,
+                         sst, sp, lw[l - 1], lh[l - 1], (void*)lv[l], dst_sst, lp[l], lw[l], lh[l], ty);
+    } else
       hipLaunchKernelGGL(pyr_down_kernel, grid, dim3(256), 0, s, src, sst, sp, lw[l - 1], lh[l - 1], lv[l], dst_sst,
                          lp[l], lw[l], lh[l]);
   }
@@ -319,10 +328,11 @@ int lssd_build_pyramid(vsf_ctx* c, const FrameRef& f, uint16_t* const* lv, int s
     // basalt's level is (w >> 1) wide, cv's is (w + 1) >> 1: the same for even w, and then the right border
     // (column w -> w - 2) is the same reflection too.
     if (l == 1 && ((uintptr_t)f.ptr % 4 == 0) && f.sstride % 4 == 0 && f.pitch % 4 == 0 && c->l16w[0] % 4 == 0 &&
-        c->l16w[0] >= 8 && ((uintptr_t)lv[1] % 8 == 0) && ((long long)dw * dh) % 4 == 0)
-      hipLaunchKernelGGL(pyr_down_dword_kernel<true>, grid, dim3(256), 0, s, f.ptr, f.sstride, f.pitch, c->l16w[0],
-                         c->l16h[0], (void*)lv[1], (long long)dw * dh, dw, dw, dh);
-    else if (l == 1)
+        c->l16w[0] >= 8 && ((uintptr_t)lv[1] % 8 == 0) && ((long long)dw * dh) % 4 == 0) {
+      const int ty = pyr_tiles_y(grid.x, grid.y, streams);
+      hipLaunchKernelGGL(pyr_down_dword_kernel<true>, dim3(grid.x, (grid.y + ty - 1) / ty, streams), dim3(256), 0, s, f.ptr,
+                         f.sstride, f.pitch, c->l16w[0], c->l16h[0], (void*)lv[1], (long long)dw * dh, dw, dw, dh, ty);
+    } else if (l == 1)
       hipLaunchKernelGGL(lssd_subsample_kernel<true>, grid, dim3(256), 0, s, f.ptr, f.sstride, f.pitch, c->l16w[0],
                          c->l16h[0], lv[1], dw, dh);
     else

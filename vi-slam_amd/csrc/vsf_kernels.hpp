@@ -132,77 +132,109 @@ constexpr int PD_SD = 34;  // dwords per staged row
 // OUT16: the destination is a dense u16 level holding the UNROUNDED double sum.  That is level 1 of basalt's
 // u16 mip pyramid of the frame read as v << 8 (vsf_lssd.hpp): (sum * 256 + 128) >> 8 == sum.  dst_sstride and
 // dst_pitch are then in u16 elements.
+// A block walks `tiles_y` vertically adjacent tiles and keeps the NEXT tile's source dwords in flight (five
+// registers per thread) while it filters the current one: the kernel is HBM-bound, and with load, filter and
+// store phases strictly in turn a block had bytes in flight for well under half of its life (level 1 of 1024
+// 752x480 frames: 2.1 TB/s).
 template <bool OUT16>
 __global__ __launch_bounds__(256) void pyr_down_dword_kernel(const uint8_t* __restrict__ src, long long src_sstride,
                                                              int src_pitch, int sw, int sh,
                                                              void* __restrict__ dst, long long dst_sstride,
-                                                             int dst_pitch, int dw, int dh) {
+                                                             int dst_pitch, int dw, int dh, int tiles_y) {
   __shared__ uint32_t s_src[PD_SH * PD_SD];
   __shared__ uint32_t s_h[PD_SH * (PD_TW / 2 + 2)];
   constexpr int HP = PD_TW / 2 + 2;  // pitch of s_h in dwords (even: 8-byte reads stay aligned)
+  constexpr int NR = (PD_SH * PD_SD + 255) / 256;  // staged dwords per thread
   const int stream = blockIdx.z;
   const uint8_t* S = src + (long long)stream * src_sstride;
-  const int ox = blockIdx.x * PD_TW, oy = blockIdx.y * PD_TH;
-  const int gx_base = 2 * ox - 4, sy0 = 2 * oy - 2;
-  for (int i = threadIdx.x; i < PD_SH * PD_SD; i += 256) {
+  const int ox = blockIdx.x * PD_TW;
+  const int gx_base = 2 * ox - 4;
+  // this thread's dwords of a tile: fixed (row, column) slots, only the tile's first row changes
+  int sl_y[NR], sl_x[NR];
+#pragma unroll
+  for (int k = 0; k < NR; k++) {
+    const int i = threadIdx.x + 256 * k;
     const int y = i / PD_SD, j = i - y * PD_SD;
-    int gy = reflect101(sy0 + y, sh);
-    gy = min(max(gy, 0), sh - 1);  // rows that only feed outputs below the image
     const int gx = gx_base + 4 * j;
-    uint32_t v = 0;
-    if (gx >= 0 && gx + 4 <= sw) v = *reinterpret_cast<const uint32_t*>(S + (long long)gy * src_pitch + gx);
-    s_src[i] = v;
+    sl_y[k] = (i < PD_SH * PD_SD) ? y : -1;
+    sl_x[k] = (gx >= 0 && gx + 4 <= sw) ? gx : -1;
   }
-  __syncthreads();
-  if (gx_base + 2 < 0 || gx_base + PD_SW + 2 > sw) {  // block-uniform: the tile crosses the left / right image edge
-    uint8_t* sb = reinterpret_cast<uint8_t*>(s_src);
-    for (int i = threadIdx.x; i < PD_SH * 8; i += 256) {
-      const int y = i >> 3, k = i & 7;
-      // candidates: tile columns 2, 3 (gx = 2ox-2, 2ox-1) on the left, and the first four past sw on the right
-      const int t = k < 2 ? 2 + k : (sw - gx_base) + (k - 2);
-      const int gx = gx_base + t;
-      if (t >= 2 && t < 2 + PD_SW && (gx < 0 || gx >= sw) && k < 6) {
-        const int tr = min(max(reflect101(gx, sw) - gx_base, 0), 4 * PD_SD - 1);
-        sb[y * 4 * PD_SD + t] = sb[y * 4 * PD_SD + tr];
+  uint32_t nxt[NR];
+  auto fetch = [&](int oy) {
+    const int sy0 = 2 * oy - 2;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+      uint32_t v = 0;
+      if (sl_y[k] >= 0 && sl_x[k] >= 0) {
+        int gy = reflect101(sy0 + sl_y[k], sh);
+        gy = min(max(gy, 0), sh - 1);  // rows that only feed outputs below the image
+        v = *reinterpret_cast<const uint32_t*>(S + (long long)gy * src_pitch + sl_x[k]);
       }
+      nxt[k] = v;
     }
+  };
+  const int ty0 = blockIdx.y * tiles_y;
+  if (ty0 * PD_TH >= dh) return;
+  fetch(ty0 * PD_TH);
+  for (int t = 0; t < tiles_y; t++) {
+    const int oy = (ty0 + t) * PD_TH;
+    if (oy >= dh) break;  // block-uniform
+#pragma unroll
+    for (int k = 0; k < NR; k++)
+      if (sl_y[k] >= 0) s_src[threadIdx.x + 256 * k] = nxt[k];
     __syncthreads();
-  }
-  for (int i = threadIdx.x; i < PD_SH * (PD_TW / 2); i += 256) {
-    const int y = i >> 5, p = i & 31;  // outputs 2p, 2p+1 of row y: tile columns 4p+2 .. 4p+8
-    const uint32_t* r = s_src + y * PD_SD + p;
-    const uint32_t a = r[0], b = r[1], c = r[2];
-    const uint32_t b0 = a >> 16 & 255, b1 = a >> 24, b2 = b & 255, b3 = b >> 8 & 255, b4 = b >> 16 & 255, b5 = b >> 24,
-                   b6 = c & 255;
-    const uint32_t h0 = b0 + 4 * b1 + 6 * b2 + 4 * b3 + b4, h1 = b2 + 4 * b3 + 6 * b4 + 4 * b5 + b6;
-    s_h[y * HP + p] = h0 | (h1 << 16);
-  }
-  __syncthreads();
-  {
-    const int y = threadIdx.x >> 4, q = threadIdx.x & 15;  // outputs 4q .. 4q+3 of row y
-    const int gx = ox + 4 * q, gy = oy + y;
-    if (gx < dw && gy < dh) {
-      const uint32_t* c = s_h + (2 * y) * HP + 2 * q;
-      uint32_t lo = c[0] + c[4 * HP] + 4 * (c[HP] + c[3 * HP]) + 6 * c[2 * HP];
-      uint32_t hi = c[1] + c[4 * HP + 1] + 4 * (c[HP + 1] + c[3 * HP + 1]) + 6 * c[2 * HP + 1];
-      if (OUT16) {
-        uint16_t* D = reinterpret_cast<uint16_t*>(dst) + (long long)stream * dst_sstride + (long long)gy * dst_pitch + gx;
-        if ((dst_pitch & 3) == 0) {  // gx is a multiple of 4 and < dw: the four outputs exist, 8-byte aligned
-          *reinterpret_cast<uint2*>(D) = make_uint2(lo, hi);
-        } else {
-          D[0] = (uint16_t)lo;
-          if (gx + 1 < dw) D[1] = (uint16_t)(lo >> 16);
-          if (gx + 2 < dw) D[2] = (uint16_t)hi;
-          if (gx + 3 < dw) D[3] = (uint16_t)(hi >> 16);
+    if (t + 1 < tiles_y && oy + PD_TH < dh) fetch(oy + PD_TH);  // in flight during the two passes below
+    if (gx_base + 2 < 0 || gx_base + PD_SW + 2 > sw) {  // block-uniform: the tile crosses the left / right image edge
+      uint8_t* sb = reinterpret_cast<uint8_t*>(s_src);
+      for (int i = threadIdx.x; i < PD_SH * 8; i += 256) {
+        const int y = i >> 3, k = i & 7;
+        // candidates: tile columns 2, 3 (gx = 2ox-2, 2ox-1) on the left, and the first four past sw on the right
+        const int tc = k < 2 ? 2 + k : (sw - gx_base) + (k - 2);
+        const int gx = gx_base + tc;
+        if (tc >= 2 && tc < 2 + PD_SW && (gx < 0 || gx >= sw) && k < 6) {
+          const int tr = min(max(reflect101(gx, sw) - gx_base, 0), 4 * PD_SD - 1);
+          sb[y * 4 * PD_SD + tc] = sb[y * 4 * PD_SD + tr];
         }
-      } else {
-        uint8_t* D = reinterpret_cast<uint8_t*>(dst) + (long long)stream * dst_sstride;
-        lo = (lo + 0x00800080u) >> 8 & 0x00ff00ffu;
-        hi = (hi + 0x00800080u) >> 8 & 0x00ff00ffu;
-        const uint32_t out = (lo & 255) | (lo >> 16 << 8) | (hi & 255) << 16 | (hi >> 16 << 24);
-        *reinterpret_cast<uint32_t*>(D + (long long)gy * dst_pitch + gx) = out;  // dst_pitch = roundup4(dw): pad bytes
+      }
+      __syncthreads();
+    }
+    for (int i = threadIdx.x; i < PD_SH * (PD_TW / 2); i += 256) {
+      const int y = i >> 5, p = i & 31;  // outputs 2p, 2p+1 of row y: tile columns 4p+2 .. 4p+8
+      const uint32_t* r = s_src + y * PD_SD + p;
+      const uint32_t a = r[0], b = r[1], c = r[2];
+      const uint32_t b0 = a >> 16 & 255, b1 = a >> 24, b2 = b & 255, b3 = b >> 8 & 255, b4 = b >> 16 & 255, b5 = b >> 24,
+                     b6 = c & 255;
+      const uint32_t h0 = b0 + 4 * b1 + 6 * b2 + 4 * b3 + b4, h1 = b2 + 4 * b3 + 6 * b4 + 4 * b5 + b6;
+      s_h[y * HP + p] = h0 | (h1 << 16);
+    }
+    __syncthreads();  // also: every read of s_src is done before the next tile overwrites it
+    {
+      const int y = threadIdx.x >> 4, q = threadIdx.x & 15;  // outputs 4q .. 4q+3 of row y
+      const int gx = ox + 4 * q, gy = oy + y;
+      if (gx < dw && gy < dh) {
+        const uint32_t* c = s_h + (2 * y) * HP + 2 * q;
+        uint32_t lo = c[0] + c[4 * HP] + 4 * (c[HP] + c[3 * HP]) + 6 * c[2 * HP];
+        uint32_t hi = c[1] + c[4 * HP + 1] + 4 * (c[HP + 1] + c[3 * HP + 1]) + 6 * c[2 * HP + 1];
+        if (OUT16) {
+          uint16_t* D = reinterpret_cast<uint16_t*>(dst) + (long long)stream * dst_sstride + (long long)gy * dst_pitch + gx;
+          if ((dst_pitch & 3) == 0) {  // gx is a multiple of 4 and < dw: the four outputs exist, 8-byte aligned
+            *reinterpret_cast<uint2*>(D) = make_uint2(lo, hi);
+          } else {
+            D[0] = (uint16_t)lo;
+            if (gx + 1 < dw) D[1] = (uint16_t)(lo >> 16);
+            if (gx + 2 < dw) D[2] = (uint16_t)hi;
+            if (gx + 3 < dw) D[3] = (uint16_t)(hi >> 16);
+          }
+        } else {
+          uint8_t* D = reinterpret_cast<uint8_t*>(dst) + (long long)stream * dst_sstride;
+          lo = (lo + 0x00800080u) >> 8 & 0x00ff00ffu;
+          hi = (hi + 0x00800080u) >> 8 & 0x00ff00ffu;
+          const uint32_t out = (lo & 255) | (lo >> 16 << 8) | (hi & 255) << 16 | (hi >> 16 << 24);
+          *reinterpret_cast<uint32_t*>(D + (long long)gy * dst_pitch + gx) = out;  // dst_pitch = roundup4(dw): pad bytes
+        }
       }
     }
+    // s_h is rewritten only after the next tile's first barrier, which every thread reaches after these reads
   }
 }
 
