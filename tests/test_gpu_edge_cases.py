@@ -230,3 +230,36 @@ def test_vsf_step_equals_track_then_detect(vsf, oracle, synth):
             assert tuple(stats) == tuple(trk.last_stats)
     assert a.n > 50
     one.close()
+
+
+@pytest.mark.parametrize("w,h,rows,cols", [
+    (63, 15, 1, 1), (64, 16, 1, 1), (65, 17, 1, 1), (66, 18, 1, 1),     # one tile, one tile + 1, 2, 3 positions
+    (125, 29, 1, 1), (126, 30, 1, 1), (127, 31, 1, 1), (190, 44, 1, 1),  # around two and three tile steps (62 x 14)
+    (9, 7, 1, 1), (5, 130, 1, 1), (130, 5, 1, 1), (4, 4, 1, 1),          # cells only a few pixels across
+    (26, 22, 8, 8), (40, 9, 3, 13),                                     # cells of 2..4 pixels: no mirrored halo fits
+])
+def test_detector_tile_geometry(vsf, oracle, w, h, rows, cols):
+    """The score kernel's tiling (64 x 16 lambda blocks stepping 62 x 14 from cell position 0, REFLECT_101 products
+    mirrored at the cell border, the generic path of cells under 4 pixels): lambda map and detector output of
+    cells whose sizes sit on and next to every tile boundary, against the oracle."""
+    rng = np.random.default_rng(w * 1000 + h)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    img[h // 3: h // 3 + 3, :] = 200          # flat bands: skipped square roots, equal neighbours
+    p = vsf.default_params(width=w, height=h, grid_rows=rows, grid_cols=cols, max_features=rows * cols * 6,
+                           min_distance=1.5, klt_win=3, klt_max_level=0)
+    ctx = vsf.Context(p)
+    rects, _ = oracle.generate_grid(w, h, cols, rows)
+    for c, rect in enumerate(rects):
+        got, grect = ctx.debug_min_eig(img, c)
+        assert tuple(int(v) for v in rect) == grect
+        ref = oracle.corner_min_eigen_val(img, rect)
+        assert np.array_equal(got.view(np.uint32), ref.view(np.uint32)), "cell %d" % c
+    cap = ctx.capacity
+    ids, xy, age = _table(cap)
+    n = ctx.detect(img, ids, xy, age, 0)
+    det = oracle.Detector(rows, cols, rows * cols * 6, 1.5)
+    T = oracle.FeatureTable(cap)
+    assert det.update_detection(T, img) == 0
+    assert n == T.n.value
+    assert np.array_equal(ids[:n], T.ids[:n]) and np.array_equal(xy[:n], T.xy[:n]) and np.array_equal(age[:n], T.age[:n])
+    ctx.close()
