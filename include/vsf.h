@@ -67,7 +67,7 @@ typedef struct vsf_params {
    * radius is int(min_distance) <= 31); the fields below are the rest of its Parameter (:23-34).
    * detection_min_feature_distance_ is fixed at the reference's 1.0 and Harris is off (:24,27). */
   int32_t detector_kind;
-  int32_t anms_detection_features; /* detection_feature_number_; 0 = 2 * max_features (:23); <= 4096 */
+  int32_t anms_detection_features; /* detection_feature_number_; 0 = 2 * max_features (:23); <= 8192 */
   double anms_quality_level;       /* detection_quality_level_ 0.001 (:25) */
   int32_t anms_block_size;         /* detection_block_size_ 4 (:26); 3 or 4 */
   int32_t anms_ignore_edge;        /* detection_ignore_edge_ 20 (:29) */

@@ -14,10 +14,11 @@ for cfg in C3 C4 C5; do
 done
 timeout -k 10 300 python3 -u bench.py --no-cpu --tracker lssd > $out/${tag}_bench_lssd.json 2> $out/${tag}_bench_lssd.err || exit 1
 timeout -k 10 300 python3 -u bench.py --no-cpu --detector anms --tracker lssd > $out/${tag}_bench_anms_lssd.json 2> $out/${tag}_bench_anms_lssd.err || exit 1
+timeout -k 10 600 python3 -u bench.py --no-cpu --config C4 --detector anms > $out/${tag}_bench_C4_anms.json 2> $out/${tag}_bench_C4_anms.err || exit 1
 timeout -k 10 300 python3 -u bench.py --no-cpu --occlusion 0 > $out/${tag}_bench_C2_noocc.json 2> $out/${tag}_bench_C2_noocc.err || exit 1
 # --gpus 2 on a one-GPU box must fail loudly, not report n_gpus 1
 timeout -k 10 120 python3 -u bench.py --gpus 2 --no-cpu > $out/${tag}_bench_gpus2.out 2> $out/${tag}_bench_gpus2.err; echo "gpus2 exit code $?" | tee $out/${tag}_bench_gpus2.rc
-for f in C2 C3 C4 C5 lssd anms_lssd C2_noocc; do python3 -c "
+for f in C2 C3 C4 C5 lssd anms_lssd C4_anms C2_noocc; do python3 -c "
 import json,sys
 d=json.load(open('$out/${tag}_bench_$f.json'))
 print('$f', round(d['value']), 'frames/s', round(d['ms_per_step'],3),'ms', 'verified', round(d['config']['verified_fraction'],4), 'lk', round(d['kernel_ms']['lk'],3), 'score', round(d['kernel_ms']['score'],3), 'frac', round(d['roofline']['frac'],4), 'cpu', d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('single_thread',{}).get('value'))

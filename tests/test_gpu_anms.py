@@ -17,9 +17,10 @@ def _table(cap):
 
 @pytest.mark.parametrize("w,h,maxn,mind", [(752, 480, 300, 10.0), (320, 240, 100, 10.0), (401, 303, 150, 7.5),
                                            (640, 480, 500, 4.0),
-                                           (1280, 720, 2000, 6.0)])  # 4000 detected keypoints: the LDS-resident limit
+                                           (1280, 720, 2000, 6.0),   # 4000 detected keypoints
+                                           (3840, 2160, 4000, 12.0)])  # BASELINE C4: 8000 keypoints (limit 8192)
 def test_anms_sequence_bit_exact(vsf, oracle, synth, w, h, maxn, mind):
-    frames, _ = synth.sequence(21, w, h, 4)
+    frames, _ = synth.sequence(21, w, h, 4 if w < 3000 else 3)
     ctx = vsf.Context(_params(vsf, w, h, maxn, mind))
     cap = ctx.capacity
     ids, xy, age = _table(cap)

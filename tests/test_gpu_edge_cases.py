@@ -97,7 +97,7 @@ def test_error_returns(vsf, synth):
     with pytest.raises(vsf.VsfError):
         vsf.Context(vsf.default_params(detector_kind=7))
     with pytest.raises(vsf.VsfError):
-        vsf.Context(vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, max_features=2100))  # 4200 > 4096 keypoints
+        vsf.Context(vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, max_features=4100))  # 8200 > 8192 keypoints
     with pytest.raises(vsf.VsfError):
         vsf.Context(vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, min_distance=40.0))  # disc radius > 31
     ctx = vsf.Context(vsf.default_params(width=200, height=150))

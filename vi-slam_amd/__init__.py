@@ -360,7 +360,7 @@ class Context:
         """(mask GFTT saw [h][w], detected keypoints [n][2] in cv order) of the last ANMS detection."""
         w, h = self.params.width, self.params.height
         flag = np.zeros((h, w), np.uint8)
-        kp = np.zeros((4096, 2), np.int16)
+        kp = np.zeros((8192, 2), np.int16)
         n = C.c_int32(0)
         self._chk(lib().vsf_debug_anms(self._h, stream, _vp(flag), _vp(kp), C.byref(n)))
         return flag, kp[:n.value].copy()

@@ -249,14 +249,18 @@ __device__ __forceinline__ int introsort_equal_src(int n, int p) {
 __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict__ kp, const int* __restrict__ ndet,
                                                        const int* __restrict__ n_tab, AnmsParams ap,
                                                        double2* __restrict__ sel_xy, int* __restrict__ sel_cnt) {
+  // LDS, 17 bytes per keypoint slot (139 KB at 8192): positions, the cell of every keypoint at the current width,
+  // a hash of occupied cells whose entries hold only the index of the cell's first keypoint (its key is read back
+  // from that keypoint's cell), the per-keypoint state.  The result list of a width shares the hash's space: the
+  // hash is dead once the rounds are over, and a later width rebuilds it only when its own result replaces the list.
   extern __shared__ __align__(16) uint8_t smem[];
-  short* sx = reinterpret_cast<short*>(smem);
+  unsigned int* cell = reinterpret_cast<unsigned int*>(smem);                    // [kcap] row << 16 | col
+  unsigned int* hown = cell + ap.kcap;                                           // [hash_size] owner index or EMPTY
+  unsigned short* res = reinterpret_cast<unsigned short*>(hown);                 // [kcap], after the rounds
+  short* sx = reinterpret_cast<short*>(hown + ap.hash_size);
   short* sy = sx + ap.kcap;
-  unsigned short* slot = reinterpret_cast<unsigned short*>(sy + ap.kcap);
-  unsigned short* res = slot + ap.kcap;
-  unsigned int* hkey = reinterpret_cast<unsigned int*>(res + ap.kcap);
-  unsigned int* hval = hkey + ap.hash_size;
-  volatile uint8_t* state = reinterpret_cast<volatile uint8_t*>(hval + ap.hash_size);
+  volatile uint8_t* state = reinterpret_cast<volatile uint8_t*>(sy + ap.kcap);
+  constexpr unsigned int EMPTY = 0xffffffffu;
   __shared__ int s_low, s_high, s_width, s_prev, s_done, s_nres, s_base;
   __shared__ unsigned int s_kmin, s_kmax;
   __shared__ int s_wave[4];
@@ -311,50 +315,54 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
     __syncthreads();
     if (s_done) break;
     const int width = s_width;
-    for (int i = threadIdx.x; i < ap.hash_size; i += 256) {
-      hkey[i] = 0xffffffffu;
-      hval[i] = 0xffffffffu;
-    }
-    __syncthreads();
+    for (int i = threadIdx.x; i < ap.hash_size; i += 256) hown[i] = EMPTY;
     for (int i = threadIdx.x; i < n; i += 256) {
       const unsigned int row = (unsigned int)(2 * (int)sy[i]) / (unsigned int)width;
       const unsigned int col = (unsigned int)(2 * (int)sx[i]) / (unsigned int)width;
-      const unsigned int key = (row << 16) | col;
-      unsigned int h = (key * 2654435761u) >> (32 - ap.hash_bits);
-      for (;;) {
-        const unsigned int old = atomicCAS(&hkey[h], 0xffffffffu, key);
-        if (old == 0xffffffffu || old == key) break;
-        h = (h + 1) & (unsigned int)(ap.hash_size - 1);
-      }
-      slot[i] = (unsigned short)h;
-      atomicMin(&hval[h], (unsigned int)i);
+      cell[i] = (row << 16) | col;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) state[i] = (hval[slot[i]] == (unsigned int)i) ? 0 : 2;  // 0 U, 1 A, 2 R
+    // every owner a slot ever has lies in the same cell, so the slot's key can be read through any of them
+    auto find_or_claim = [&](unsigned int key, unsigned int i) -> unsigned int {
+      unsigned int h = (key * 2654435761u) >> (32 - ap.hash_bits);
+      for (;;) {
+        unsigned int e = hown[h];
+        if (e == EMPTY) {
+          e = atomicCAS(&hown[h], EMPTY, i);
+          if (e == EMPTY) return h;
+        }
+        if (cell[e] == key) {
+          atomicMin(&hown[h], i);
+          return h;
+        }
+        h = (h + 1) & (unsigned int)(ap.hash_size - 1);
+      }
+    };
+    auto owner_of = [&](unsigned int key) -> unsigned int {
+      unsigned int h = (key * 2654435761u) >> (32 - ap.hash_bits);
+      for (;;) {
+        const unsigned int e = hown[h];
+        if (e == EMPTY) return EMPTY;
+        if (cell[e] == key) return e;
+        h = (h + 1) & (unsigned int)(ap.hash_size - 1);
+      }
+    };
+    for (int i = threadIdx.x; i < n; i += 256) (void)find_or_claim(cell[i], (unsigned int)i);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) state[i] = (owner_of(cell[i]) == (unsigned int)i) ? 0 : 2;  // 0 U, 1 A, 2 R
     __syncthreads();
     for (;;) {
       int undecided = 0;
       for (int i = threadIdx.x; i < n; i += 256) {
         if (state[i] != 0) continue;
-        const int row = (2 * (int)sy[i]) / width, col = (2 * (int)sx[i]) / width;
+        const int row = (int)(cell[i] >> 16), col = (int)(cell[i] & 0xffffu);
         bool rejected = false, blocked = false;
         for (int dr = -2; dr <= 2 && !rejected; dr++)
           for (int dc = -2; dc <= 2; dc++) {
             if (dr == 0 && dc == 0) continue;
             const int rr = row + dr, cc = col + dc;
             if (rr < 0 || cc < 0) continue;
-            const unsigned int key = ((unsigned int)rr << 16) | (unsigned int)cc;
-            unsigned int h = (key * 2654435761u) >> (32 - ap.hash_bits);
-            unsigned int j = 0xffffffffu;
-            for (;;) {
-              const unsigned int k2 = hkey[h];
-              if (k2 == 0xffffffffu) break;
-              if (k2 == key) {
-                j = hval[h];
-                break;
-              }
-              h = (h + 1) & (unsigned int)(ap.hash_size - 1);
-            }
+            const unsigned int j = owner_of(((unsigned int)rr << 16) | (unsigned int)cc);
             if (j < (unsigned int)i) {
               const uint8_t st = state[j];
               if (st == 1) {

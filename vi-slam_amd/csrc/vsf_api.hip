@@ -479,7 +479,7 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
   return VSF_OK;
 }
 
-int anms_ssc_smem(const AnmsParams& a) { return a.kcap * (2 + 2 + 2 + 2 + 1) + a.hash_size * 8 + 16; }
+int anms_ssc_smem(const AnmsParams& a) { return a.kcap * (4 + 2 + 2 + 1) + a.hash_size * 4 + 16; }
 
 // FeatureDetectorANMS::Detect on `streams` streams (ref: FeatureDetectorANMS.cpp:69-212)
 int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long mask_sstride, int mask_pitch,
@@ -787,7 +787,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   int anms_k = 0;
   if (use_anms) {
     anms_k = p->anms_detection_features > 0 ? p->anms_detection_features : 2 * p->max_features;
-    if (anms_k < 1 || anms_k > 4096 || (int)p->min_distance > ANMS_MAX_RADIUS || (int)p->min_distance < 0)
+    if (anms_k < 1 || anms_k > 8192 || (int)p->min_distance > ANMS_MAX_RADIUS || (int)p->min_distance < 0)
       return VSF_E_INVALID;
     if (p->anms_block_size != 3 && p->anms_block_size != 4) return VSF_E_INVALID;
     if (!(p->anms_quality_level >= 0.0) || p->anms_quality_level > 1.0 || !(p->anms_tolerance >= 0.0) ||
