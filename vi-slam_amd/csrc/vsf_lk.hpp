@@ -402,7 +402,10 @@ __device__ __forceinline__ void region_load_regs(unsigned int (&reg)[N], const u
   const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
   const unsigned int* s = reinterpret_cast<const unsigned int*>(src + (long long)y0 * sp + xa);
   const unsigned int spw = (unsigned int)sp >> 2;
-  const unsigned int off = (unsigned int)yl * spw + (unsigned int)xd, step = (unsigned int)ystep * spw;
+  // rows and pitches are far below 2^24: v_mad_u32_u24, not the 64-bit multiply-add a plain 32-bit product takes.
+  // (Buffer loads with a wave-uniform descriptor and out-of-range offsets for the idle lanes -- no exec-mask
+  // branches, 32-bit offsets -- were tried here: bit-exact, 6 % SLOWER on the whole kernel.)
+  const unsigned int off = __umul24((unsigned int)yl, spw) + (unsigned int)xd, step = (unsigned int)ystep * spw;
   const bool xin = xd < g.ndw;
 #pragma unroll
   for (int i = 0; i < N; i++) {
@@ -495,6 +498,14 @@ __device__ __forceinline__ void region_stage_slow_pairs(unsigned int* dst, const
       for (int k = 0; k < 4; k++) d[k] = b[k] | (b[k + 1] << 16);
     }
   }
+}
+
+// (int)f of a wave-uniform float as a scalar.  Written through an opaque VGPR: left alone, the compiler moves the
+// lane read in front of the conversion (v_readfirstlane, v_cvt with a scalar operand, v_readfirstlane again).
+__device__ __forceinline__ int uniform_f2i(float f) {
+  int i = (int)f;
+  asm volatile("" : "+v"(i));
+  return __builtin_amdgcn_readfirstlane(i);
 }
 
 // One wave's LDS ordering point: LDS operations of a wave execute in issue order, so a store by one lane is seen
@@ -624,12 +635,17 @@ __device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, cons
     // Generic path (window touches the level border): Scharr gradient patch (win+1)^2 in LDS,
     // zero outside the level image (BORDER_CONSTANT), then the bilinear template per lane.
     {
+      // an opaque zero defined HERE: what derives from it cannot be scheduled above the branch, where the
+      // interior path (the common one) would pay for this path's two dozen address instructions
+      int oz;
+      asm volatile("v_mov_b32 %0, 0" : "=v"(oz));
+      const int lane_g = lane + oz;
       const int side = win + 1;
-      const int xs = lane & 31;
+      const int xs = lane_g & 31;
       if (xs < side) {
         const int gx = ipx + xs;
         const bool xin = gx >= 0 && gx < aw;
-        for (int y = lane >> 5; y < side; y += 2) {
+        for (int y = lane_g >> 5; y < side; y += 2) {
           const int gy = ipy + y;
           int packed = 0;
           if (xin && gy >= 0 && gy < ah) {
@@ -853,8 +869,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     py -= half;
     // the floor as a float serves the fraction below: (float)ip == floorf(p) wherever the point is in range
     const float fpx = floorf(px), fpy = floorf(py);
-    const int ipx = __builtin_amdgcn_readfirstlane((int)fpx);
-    const int ipy = __builtin_amdgcn_readfirstlane((int)fpy);
+    const int ipx = uniform_f2i(fpx);
+    const int ipy = uniform_f2i(fpy);
     const int aw = A.w[level], ah = A.h[level];
     const bool in_range = !(ipx < -win || ipx >= aw || ipy < -win || ipy >= ah);
     const bool cached = (SEG <= 8) && tc.rd_hdr != nullptr;  // wave-uniform
@@ -955,8 +971,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       float pdx = 0.f, pdy = 0.f;
       for (int j = 0; j < prm.max_count; j++) {
         const float fcx = floorf(cx), fcy = floorf(cy);
-        const int inx = __builtin_amdgcn_readfirstlane((int)fcx);
-        const int iny = __builtin_amdgcn_readfirstlane((int)fcy);
+        const int inx = uniform_f2i(fcx);
+        const int iny = uniform_f2i(fcy);
         if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
           if (level == 0) status = false;
           end_kind = 8;
