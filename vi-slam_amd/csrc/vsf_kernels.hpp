@@ -672,7 +672,9 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   if ((threadIdx.x & 63) == 0 && local_max) atomicMax(&s_max, local_max);
   __syncthreads();
   const unsigned int blk_max = s_max;
-  if (threadIdx.x == 0 && blk_max) atomicMax(cmax, blk_max);
+  // (a block that cannot raise the maximum it saw at its start sends no atomic: with the whole frame as ONE cell
+  // -- the ANMS detector -- thousands of tiles would otherwise queue on one address)
+  if (threadIdx.x == 0 && blk_max > seen) atomicMax(cmax, blk_max);
   if (!EMIT) return;
   // ---- candidates of the inner 62 x 14 positions
   const unsigned int lb = max(seen, blk_max);  // lower bound of the cell's final masked maximum (0: none yet)
