@@ -791,6 +791,9 @@ __device__ __forceinline__ bool lk_converged(float dx, float dy, const LkParams&
   const float s = __fmaf_rn(dx, dx, dy * dy);
   if (s <= prm.eps2_lo) return true;
   if (s >= prm.eps2_hi) return false;
+  // an empty volatile asm gives the rare block a side effect: it cannot be if-converted into the common path (where
+  // its seven double-precision instructions ran in every iteration that did not converge)
+  asm volatile("");
   return (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2;
 }
 
