@@ -16,5 +16,5 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS S
   python3 tools/pmc_summary.py /tmp/prof_$tag/$name $out/prof_${tag}_pmc_$name.csv | grep "vsf::" > /dev/null
   grep "^kernel\|vsf::" $out/prof_${tag}_pmc_$name.csv > $out/tmp.csv && mv $out/tmp.csv $out/prof_${tag}_pmc_$name.csv
 done
-tail -1 $out/prof_${tag}_bench.log
+grep "^{\"metric\"" $out/prof_${tag}_bench.log | tail -1
 cat $out/prof_${tag}_kernel_stats.csv | cut -c1-200
