@@ -2,10 +2,6 @@
 // Included by vsf_kernels.hpp after the common declarations (PyrView, LkParams, reflect101).
 #pragma once
 
-#ifndef VSF_LK_PREFETCH_J
-#define VSF_LK_PREFETCH_J 0
-#endif
-
 namespace vsf {
 
 // ------------------------------------------------------------------------------------------------
@@ -886,24 +882,6 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     const int bp = B.pitch[level], bw = B.w[level], bh = B.h[level];
     bool level_ok = in_range;
     if (!in_range && level == 0) status = false;
-#if VSF_LK_PREFETCH_J
-    // The first J region of the level is known before the template exists (it depends on nextPt only): issue its
-    // loads now, so that their latency runs under the template work instead of in front of the first iteration.
-    constexpr int NJP = (SEG <= 8) ? 4 : 10;
-    unsigned int rjp[NJP];
-    int pjx0 = 0, pjy0 = 0;
-    bool pre = false;
-    if (in_range) {
-      const int pinx = __builtin_amdgcn_readfirstlane((int)floorf(nx - half));
-      const int piny = __builtin_amdgcn_readfirstlane((int)floorf(ny - half));
-      pjx0 = (pinx - prm.jmargin) & ~3;
-      pjy0 = piny - prm.jmargin;
-      if (!(pinx < -win || pinx >= bw || piny < -win || piny >= bh) && region_is_fast(Bb, bp, bw, bh, pjx0, pjy0, L.gj)) {
-        region_load_regs<NJP>(rjp, Bb, bp, pjx0, pjy0, L.gj, lane);
-        pre = true;
-      }
-    }
-#endif
 
     unsigned int IxP[NP], IyP[NP];  // template gradients, pair-packed, zero where the lane owns no pixel
     int cI1 = 0, cI2 = 0;
@@ -987,15 +965,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           lk_wave_sync();  // previous iteration's reads are done
           jx0 = (inx - prm.jmargin) & ~3;
           jy0 = iny - prm.jmargin;
-#if VSF_LK_PREFETCH_J
-          if (pre && jx0 == pjx0 && jy0 == pjy0)
-            region_store_pairs<NJP>(sJ, rjp, L.gj, L.jp_pitch, lane);
-          else
-#endif
-            lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
-#if VSF_LK_PREFETCH_J
-          pre = false;
-#endif
+          lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
           staged = true;
           VSF_LKSTAT(level * 16 + 3);
           lk_wave_sync();
