@@ -197,3 +197,41 @@ def test_template_cache_invalidation(vsf, oracle, synth):
             ctx.batch_upload(ids, xy, age, n)
     assert (ctx.batch_status() == 0).all()
     ctx.close()
+
+
+def test_full_c2_batch_by_replication(vsf, oracle, synth):
+    """BASELINE configs[1] at FULL size (1024 streams of 752x480, the bench's batch) through a size-independent
+    property: the batch is 128 copies of 8 distinct sequences, interleaved, so stream s must produce the table of
+    stream s mod 8 wherever it sits in the launch grid (XCD map, template cache slots, compaction, per-stream
+    counters), and the 8 distinct streams are held to the oracle bit for bit."""
+    import torch
+    w, h, T, D, B = 752, 480, 4, 8, 1024
+    rng = np.random.default_rng(9)
+    base = np.stack([synth.sequence(4100 + b, w, h, T)[0] for b in range(D)], 1).copy()   # [T][D][H][W]
+    base = _occlude(base, rng)
+    p = vsf.default_params(grid_rows=C2_DET[0], grid_cols=C2_DET[1], max_features=C2_DET[2], min_distance=C2_DET[3],
+                           klt_max_iter=C2_TRK[0], klt_eps=C2_TRK[1], klt_win=C2_TRK[2], klt_max_level=C2_TRK[3],
+                           backtrack_thr=C2_TRK[4], width=w, height=h, streams=B)
+    ctx = vsf.Context(p)
+    dev = torch.from_numpy(base).cuda().repeat(1, B // D, 1, 1).contiguous()             # stream s = sequence s % 8
+    assert dev.shape == (T, B, h, w)
+    dets = [oracle.Detector(*C2_DET) for _ in range(D)]
+    trks = [oracle.Tracker(*C2_TRK, oracle.ACC_EXACT) for _ in range(D)]
+    tabs = [oracle.FeatureTable(ctx.capacity) for _ in range(D)]
+    for t in range(T):
+        ctx.batch_step(dev[t].data_ptr(), h * w, w, torch.cuda.current_stream().cuda_stream)
+        ids, xy, age, n, stats = ctx.batch_download()
+        for b in range(D):
+            trks[b].track(tabs[b], base[t, b])
+            dets[b].update_detection(tabs[b], base[t, b])
+            assert _tables(ids, xy, age, n, b) == tabs[b].as_dict(), "step %d stream %d" % (t, b)
+        # every replica equals its original: whole rows of the table arrays, counts and the logged statistics
+        n8 = n.reshape(B // D, D)
+        assert (n8 == n8[0]).all(), "step %d: feature counts differ between replicas" % t
+        for b in range(D):
+            k = int(n[b])
+            assert (ids[b::D, :k] == ids[b, :k]).all() and (age[b::D, :k] == age[b, :k]).all()
+            assert (xy[b::D, :k] == xy[b, :k]).all(), "step %d: positions differ between replicas of %d" % (t, b)
+        assert (stats.reshape(B // D, D, -1) == stats.reshape(B // D, D, -1)[0]).all()
+    assert (ctx.batch_status() == 0).all()
+    ctx.close()
