@@ -199,24 +199,28 @@ def test_template_cache_invalidation(vsf, oracle, synth):
     ctx.close()
 
 
-def test_full_c2_batch_by_replication(vsf, oracle, synth):
-    """BASELINE configs[1] at FULL size (1024 streams of 752x480, the bench's batch) through a size-independent
-    property: the batch is 128 copies of 8 distinct sequences, interleaved, so stream s must produce the table of
-    stream s mod 8 wherever it sits in the launch grid (XCD map, template cache slots, compaction, per-stream
-    counters), and the 8 distinct streams are held to the oracle bit for bit."""
+@pytest.mark.parametrize("name,w,h,det,trk,B,D,T", [
+    ("C2", 752, 480, C2_DET, C2_TRK, 1024, 8, 4),
+    ("C3", 1280, 720, (5, 8, 1000, 8.0), (30, 0.01, 21, 3, 1.0), 256, 4, 3),
+    ("C4", 3840, 2160, (10, 16, 4000, 12.0), (30, 0.01, 21, 4, 1.0), 32, 2, 3),
+])
+def test_full_size_batch_by_replication(vsf, oracle, synth, name, w, h, det, trk, B, D, T):
+    """BASELINE configs[1..3] at FULL size (the bench's batches: 1024 streams of 752x480, 256 of 1280x720, 32 of
+    3840x2160) through a size-independent property: the batch is B / D interleaved copies of D distinct sequences, so
+    stream s must produce the table of stream s mod D wherever it sits in the launch grid (XCD map, template cache
+    slots, compaction, per-stream counters), and the D distinct streams are held to the oracle bit for bit."""
     import torch
-    w, h, T, D, B = 752, 480, 4, 8, 1024
     rng = np.random.default_rng(9)
     base = np.stack([synth.sequence(4100 + b, w, h, T)[0] for b in range(D)], 1).copy()   # [T][D][H][W]
     base = _occlude(base, rng)
-    p = vsf.default_params(grid_rows=C2_DET[0], grid_cols=C2_DET[1], max_features=C2_DET[2], min_distance=C2_DET[3],
-                           klt_max_iter=C2_TRK[0], klt_eps=C2_TRK[1], klt_win=C2_TRK[2], klt_max_level=C2_TRK[3],
-                           backtrack_thr=C2_TRK[4], width=w, height=h, streams=B)
+    p = vsf.default_params(grid_rows=det[0], grid_cols=det[1], max_features=det[2], min_distance=det[3],
+                           klt_max_iter=trk[0], klt_eps=trk[1], klt_win=trk[2], klt_max_level=trk[3],
+                           backtrack_thr=trk[4], width=w, height=h, streams=B)
     ctx = vsf.Context(p)
-    dev = torch.from_numpy(base).cuda().repeat(1, B // D, 1, 1).contiguous()             # stream s = sequence s % 8
+    dev = torch.from_numpy(base).cuda().repeat(1, B // D, 1, 1).contiguous()             # stream s = sequence s % D
     assert dev.shape == (T, B, h, w)
-    dets = [oracle.Detector(*C2_DET) for _ in range(D)]
-    trks = [oracle.Tracker(*C2_TRK, oracle.ACC_EXACT) for _ in range(D)]
+    dets = [oracle.Detector(*det) for _ in range(D)]
+    trks = [oracle.Tracker(*trk, oracle.ACC_EXACT) for _ in range(D)]
     tabs = [oracle.FeatureTable(ctx.capacity) for _ in range(D)]
     for t in range(T):
         ctx.batch_step(dev[t].data_ptr(), h * w, w, torch.cuda.current_stream().cuda_stream)
@@ -224,7 +228,7 @@ def test_full_c2_batch_by_replication(vsf, oracle, synth):
         for b in range(D):
             trks[b].track(tabs[b], base[t, b])
             dets[b].update_detection(tabs[b], base[t, b])
-            assert _tables(ids, xy, age, n, b) == tabs[b].as_dict(), "step %d stream %d" % (t, b)
+            assert _tables(ids, xy, age, n, b) == tabs[b].as_dict(), "%s step %d stream %d" % (name, t, b)
         # every replica equals its original: whole rows of the table arrays, counts and the logged statistics
         n8 = n.reshape(B // D, D)
         assert (n8 == n8[0]).all(), "step %d: feature counts differ between replicas" % t
