@@ -350,9 +350,16 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const double2* __restric
         slot = (slot + 1) & (unsigned int)(hash_size - 1);
       }
       if (fresh) {
-        for (int c = 0; c < G.ncell; c++) {
-          const int4 rc = G.rects[c];
-          if (ix >= rc.x && ix < rc.x + rc.z && iy >= rc.y && iy < rc.y + rc.w) atomicAdd(&s_cnt[c], 1);
+        // GenerateGrid's cells are a product of column intervals and row intervals (cell = column * rows + row; the
+        // rounded intervals may overlap or leave gaps, Q1): test cols + rows intervals, not cols * rows rectangles
+        for (int cx = 0; cx < G.cols; cx++) {
+          const int4 rx = G.rects[cx * G.rows];
+          if (ix >= rx.x && ix < rx.x + rx.z) {
+            for (int cy = 0; cy < G.rows; cy++) {
+              const int4 ry = G.rects[cy];
+              if (iy >= ry.y && iy < ry.y + ry.w) atomicAdd(&s_cnt[cx * G.rows + cy], 1);
+            }
+          }
         }
       }
     }
