@@ -229,7 +229,7 @@ LkParams make_lk_params(const vsf_params* p) {
   k.min_eig_thr = p->min_eig_thr;
   k.min_eig_c1 = nextafterf((float)((p->min_eig_thr > 0. ? p->min_eig_thr : 0.) * 2.0 * k.win * k.win * 1.001), INFINITY);
   k.backtrack_thr = p->backtrack_thr;
-  k.jmargin = 3;
+  k.jmargin = LK_JMARGIN;
   return k;
 }
 
@@ -286,12 +286,25 @@ int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hi
 #define VSF_LAUNCH_W(SEG)                                                                                       \
   hipLaunchKernelGGL(lk_fb_kernel<SEG>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, fgrid, \
                      streams, c->lk, c->d_fwd, c->d_flags, cache)
-  switch (lk_seg_template(c->lk.seglen)) {
-    case 7: VSF_LAUNCH_W(7); break;
-    case 8: VSF_LAUNCH_W(8); break;
-    default: VSF_LAUNCH_W(16); break;
+#define VSF_LAUNCH_WIN(SEG, WIN)                                                                                \
+  hipLaunchKernelGGL((lk_fb_kernel<SEG, WIN>), grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, \
+                     fgrid, streams, c->lk, c->d_fwd, c->d_flags, cache)
+  // the windows the reference's configurations use (cv's default 21; 15 and 24 in its examples): geometry folded
+  if (c->lk.jmargin == LK_JMARGIN && c->lk.win == 21) {
+    VSF_LAUNCH_WIN(7, 21);
+  } else if (c->lk.jmargin == LK_JMARGIN && c->lk.win == 15) {
+    VSF_LAUNCH_WIN(7, 15);
+  } else if (c->lk.jmargin == LK_JMARGIN && c->lk.win == 24) {
+    VSF_LAUNCH_WIN(16, 24);
+  } else {
+    switch (lk_seg_template(c->lk.seglen)) {
+      case 7: VSF_LAUNCH_W(7); break;
+      case 8: VSF_LAUNCH_W(8); break;
+      default: VSF_LAUNCH_W(16); break;
+    }
   }
 #undef VSF_LAUNCH_W
+#undef VSF_LAUNCH_WIN
   HIPCHK(c, hipGetLastError());
   return VSF_OK;
 }

@@ -340,12 +340,13 @@ struct LkSmem {
 };
 
 // Pixels per lane: the window row is cut into nseg = 64 / win segments of seglen pixels.
-__host__ __device__ inline int lk_seglen(int win) {
+constexpr int LK_JMARGIN = 3;  // extra margin staged around the J window (make_lk_params)
+__host__ __device__ constexpr int lk_seglen(int win) {
   const int nseg = 64 / win;
   return (win + nseg - 1) / nseg;
 }
 // Kernel instantiation (compile-time pixels per lane) that serves a given seglen.
-__host__ __device__ inline int lk_seg_template(int seglen) { return seglen <= 7 ? 7 : (seglen <= 8 ? 8 : 16); }
+__host__ __device__ constexpr int lk_seg_template(int seglen) { return seglen <= 7 ? 7 : (seglen <= 8 ? 8 : 16); }
 
 __host__ __device__ inline RegionGeom vsf_region_geom(int cols_needed, int rows) {
   RegionGeom g;
@@ -1054,12 +1055,24 @@ __device__ __forceinline__ void lk_init_masks(const LkParams& prm, uint8_t* smem
 // flags bit0 = forward found, bit1 = backward found, bit2 = verified (kept).
 // ref: FeatureTrackerLucasKanade.cpp:36-80 (forward, backward on the forward survivors, then
 // ||back - original||_2 <= threshold in double against the ORIGINAL double position).
-template <int SEG>
+// WIN > 0: an instance for that window side (and the default J margin).  The window geometry and the LDS layout
+// are then compile-time constants instead of two dozen scalar registers (the generic instance spills SGPRs into
+// VGPR lanes and reads them back with v_readlane, a vector instruction each) and fold into the address arithmetic.
+template <int SEG, int WIN = 0>
 __global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_fb_kernel(PyrView P, PyrView C, const double2* __restrict__ xy,
                                                    const int* __restrict__ n, int cap, int fgrid, int nstreams,
-                                                   LkParams prm, float2* __restrict__ fwd,
+                                                   LkParams prm_in, float2* __restrict__ fwd,
                                                    uint8_t* __restrict__ flags, LkCache cache) {
   extern __shared__ __align__(16) uint8_t smem[];
+  LkParams prm = prm_in;
+  if constexpr (WIN > 0) {
+    static_assert(lk_seg_template(lk_seglen(WIN)) == SEG, "window and pixels per lane");
+    prm.win = WIN;
+    prm.nseg = 64 / WIN;
+    prm.seglen = lk_seglen(WIN);
+    prm.nseg_inv = (65536 + 64 / WIN - 1) / (64 / WIN);
+    prm.jmargin = LK_JMARGIN;
+  }
   // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs (id % 8 share an L2), so all
   // features of one stream are given to ONE residue class: their overlapping window lines are then
   // fetched into a single L2 instead of eight.  Placement is a speed matter only.
