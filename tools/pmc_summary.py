@@ -13,7 +13,8 @@ for f in files:
         acc[(k, row["Counter_Name"])][row["Dispatch_Id"]] += float(row["Counter_Value"])
 lines = ["kernel,counter,launches,mean_per_launch"]
 for (k, c), d in sorted(acc.items()):
-    lines.append("%s,%s,%d,%.1f" % (k, c, len(d), sum(d.values()) / len(d)))
+    name = '"%s"' % k if "," in k else k   # template arguments: lk_fb_kernel<7, 21>
+    lines.append("%s,%s,%d,%.1f" % (name, c, len(d), sum(d.values()) / len(d)))
 out = "\n".join(lines)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(out + "\n")
