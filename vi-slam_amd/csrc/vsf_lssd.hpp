@@ -419,7 +419,7 @@ struct LssdState {
 };
 
 // flags as lk_fb_kernel: bit0 forward valid, bit1 backward valid, bit2 kept.  Two features per wave.
-__global__ __launch_bounds__(64) void lssd_fb_kernel(Pyr16View P, Pyr16View C, const uint64_t* __restrict__ ids,
+__global__ __launch_bounds__(64, 6) void lssd_fb_kernel(Pyr16View P, Pyr16View C, const uint64_t* __restrict__ ids,
                                                      const double2* __restrict__ xy, const int* __restrict__ n,
                                                      int cap, int fgrid, int nstreams, LssdParams prm, LssdState st,
                                                      float2* __restrict__ fwd, uint8_t* __restrict__ flags) {
