@@ -920,12 +920,21 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
   const float2 org = G.origin[cell];
   for (int a = threadIdx.x; a < accepted; a += 256) s_ok[a] = 1;
   __syncthreads();
+  const double nn_lo = md2 * (1.0 - 1e-12), nn_hi = md2 * (1.0 + 1e-12);
   for (int t = threadIdx.x; t < accepted * n0; t += 256) {
     const int a = t / n0, i = t - a * n0;
     const double px = (double)((float)s_acc_x[a] + org.x), py = (double)((float)s_acc_y[a] + org.y);
     const double2 e = xy[(long long)stream * sp.cap + i];
     const double ddx = px - e.x, ddy = py - e.y;
-    if (!(sqrt(ddx * ddx + ddy * ddy) > sp.min_dist)) s_ok[a] = 0;  // :178-180 keep iff norm > minDist
+    // :178-180 keep iff norm > minDist.  sqrt is monotone and correctly rounded, so away from a 1e-12 relative band
+    // around minDist^2 the squared distance decides; only inside the band the square root itself is taken.
+    const double d2 = ddx * ddx + ddy * ddy;
+    bool far = d2 > nn_hi;
+    if (!far && d2 >= nn_lo) {
+      asm volatile("");  // keeps the rare block a block (no if-conversion of the double square root)
+      far = sqrt(d2) > sp.min_dist;
+    }
+    if (!far) s_ok[a] = 0;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
