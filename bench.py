@@ -381,7 +381,8 @@ def cpu_baseline(frames, order, cfg):
             "single_thread": {"value": v1, "cores": t1,
                               "sample": "%d streams x %d steps, %.1f s" % (s1, k1, d1)},
             "sample": "%d streams x %d steps of the same workload, CPU oracle (restated reference CPU path, "
-                      "gcc -O3 -march=x86-64-v3 -ffp-contract=off, OpenMP over streams), %.1f s" % (sa, ka, da)}
+                      "gcc -O3 -march=x86-64-v3 -ffp-contract=off, OpenMP over streams), %.1f s; timed from the second frame "
+                      "on, i.e. including the cheaper start-up transient the GPU line's pre-roll skips" % (sa, ka, da)}
 
 
 if __name__ == "__main__":

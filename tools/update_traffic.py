@@ -39,8 +39,8 @@ out = {
             "it, round 1). Since the template cache (round 2) the backward pass writes each tracked feature's "
             "per-level template (2.5 KB a level) and the next launch's forward pass reads it back instead of "
             "rebuilding it: ~2.7 GB written and ~1.3 GB of the fetches per 1024-stream launch are that cache, "
-            "traded for 14 % fewer VALU instructions in a kernel that is VALU-issue bound (1.5 TB/s of traffic, "
-            "19 % of HBM peak, not the limit). The cache is not part of the algorithmic bytes.",
+            "traded for a third fewer VALU instructions in a kernel that is VALU-issue bound (1.6 TB/s of traffic, "
+            "20 % of HBM peak, not the limit). The cache is not part of the algorithmic bytes.",
 }
 json.dump(out, open(os.path.join(root, "profiles", "lk_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
