@@ -587,13 +587,16 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
     }
   }
   __syncthreads();
-  unsigned int local_max = 0u;
+  // the block's masked maximum as a float (-inf: none yet); lambda is finite and never -0 (a, c >= +0), so the
+  // order encoding commutes with the maximum and is applied once per thread, not once per pixel
+  float local_maxf = -INFINITY;
   const float thr_seen = (EMIT && seen) ? (float)((double)float_order_decode(seen) * quality) : -INFINITY;
   // (x, y): position inside the lambda block; (cx, cy) = (cx0 + x, cy0 + y) lies inside the cell
   auto mask_at = [&](int cx, int cy) -> bool {
     return !M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)];
   };
-  auto finish = [&](int x, int y, const double (&sum)[3], bool mk) {
+  // lam_p / msk_p: the lambda-block / mask slot the value goes to (strip threads pass a base + constant offset)
+  auto finish = [&](int x, int y, const double (&sum)[3], bool mk, float* lam_p, uint8_t* msk_p) {
     const int cx = cx0 + x, cy = cy0 + y;
     const float a = (float)sum[0] * 0.5f, b = (float)sum[1], c = (float)sum[2] * 0.5f;
     // lambda <= a + c.  Where a + c is not above quality * (the cell maximum seen at block start) the pixel passes
@@ -605,10 +608,14 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
     if (full) lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
     if (WRITE_LAM) lam_cell[cy * cw + cx] = lm;
     if (EMIT) {
-      s_lam[y * SC_LP + x] = lm;
-      s_msk[y * SC_TW + x] = mk ? 1 : 0;
+      *lam_p = lm;
+      *msk_p = mk ? 1 : 0;
     }
-    if (mk && full) local_max = max(local_max, float_order_encode(lm));
+    // (a skipped pixel's stand-in 0 may join the maximum: it is skipped only below a threshold seen >= 0, and a
+    // block maximum at or below the one seen changes nothing.)  Plain v_max_f32: fmaxf would first quiet both
+    // operands, and neither can be a NaN.
+    float cand_v = mk ? lm : -INFINITY;
+    asm("v_max_f32 %0, %0, %1" : "+v"(local_maxf) : "v"(cand_v));
   };
   // Box filter in double like cv::boxFilter for 32F input: row sum left to right, then the column of
   // row sums top to bottom.
@@ -623,6 +630,8 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
       bool mk4[4];
 #pragma unroll
       for (int o = 0; o < 4; o++) mk4[o] = mask_at(cx0 + x, min(cy0 + y0 + o, ch - 1));
+      float* lam_base = s_lam + y0 * SC_LP + x;
+      uint8_t* msk_base = s_msk + y0 * SC_TW + x;
       double rs[3][BS + 3];
 #pragma unroll
       for (int k = 0; k < BS + 3; k++) {
@@ -646,7 +655,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
 #pragma unroll
           for (int j = 1; j < BS; j++) sum[q] += rs[q][o + j];
         }
-        if (cy0 + y0 + o < ch) finish(x, y0 + o, sum, mk4[o]);
+        if (cy0 + y0 + o < ch) finish(x, y0 + o, sum, mk4[o], lam_base + o * SC_LP, msk_base + o * SC_TW);
       }
     }
   } else {
@@ -670,11 +679,12 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
             sum[q] = (j == 0) ? t : sum[q] + t;
           }
         }
-        finish(x, y, sum, mask_at(cx, cy));
+        finish(x, y, sum, mask_at(cx, cy), s_lam + y * SC_LP + x, s_msk + y * SC_TW + x);
       }
     }
   }
   // wave max, then one LDS atomic per wave, one global atomic per block
+  unsigned int local_max = local_maxf == -INFINITY ? 0u : float_order_encode(local_maxf);
   for (int m = 32; m >= 1; m >>= 1) local_max = max(local_max, (unsigned int)__shfl_xor((int)local_max, m, 64));
   if ((threadIdx.x & 63) == 0 && local_max) atomicMax(&s_max, local_max);
   __syncthreads();
