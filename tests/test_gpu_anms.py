@@ -131,6 +131,38 @@ def test_anms_batch_matches_single(vsf, oracle, synth):
     assert (ctx.batch_status() == 0).all()
 
 
+@pytest.mark.parametrize("B", [512, 1024])
+def test_anms_many_streams_by_replication(vsf, oracle, synth, B):
+    """The top-K and SSC kernels run one workgroup per stream whose size the library picks from the stream count
+    (1024 threads below 512 streams -- every other test here --, 512 below 1024, 256 from 1024 on: the bench's batch).
+    B interleaved copies of 4 distinct sequences: the 4 are held to the oracle, every replica to its original."""
+    import torch
+    w, h, maxn, D, T = 240, 176, 120, 4, 4
+    base = np.stack([synth.sequence(700 + b, w, h, T)[0] for b in range(D)], 1).copy()   # [T][D][H][W]
+    ctx = vsf.Context(_params(vsf, w, h, maxn, 8.0, streams=B))
+    cap = ctx.capacity
+    dev = torch.from_numpy(base).cuda().repeat(1, B // D, 1, 1).contiguous()
+    dets = [oracle.AnmsDetector(maxn, 8.0) for _ in range(D)]
+    trks = [oracle.Tracker(30, 0.01, 21, 3, 1.0, acc_mode=oracle.ACC_EXACT) for _ in range(D)]
+    tabs = [oracle.FeatureTable(cap) for _ in range(D)]
+    for t in range(T):
+        ctx.batch_step(dev[t].data_ptr(), w * h, w, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ids, xy, age, n, _ = ctx.batch_download()
+        for b in range(D):
+            trks[b].track(tabs[b], base[t, b])
+            dets[b].update_detection(tabs[b], base[t, b])
+            m = tabs[b].n.value
+            assert n[b] == m, "step %d stream %d" % (t, b)
+            assert np.array_equal(ids[b, :m], tabs[b].ids[:m]) and np.array_equal(xy[b, :m], tabs[b].xy[:m])
+            assert np.array_equal(age[b, :m], tabs[b].age[:m])
+            assert (n[b::D] == m).all()
+            assert (ids[b::D, :m] == ids[b, :m]).all() and (xy[b::D, :m] == xy[b, :m]).all()
+            assert (age[b::D, :m] == age[b, :m]).all()
+    assert (ctx.batch_status() == 0).all()
+    ctx.close()
+
+
 def test_anms_golden_fixtures_on_gpu(vsf):
     """The committed golden vectors (tests/golden/*.npz, generated from the oracle) through the C ABI."""
     import glob

@@ -40,27 +40,34 @@ __global__ __launch_bounds__(256) void anms_mask_kernel(const uint8_t* __restric
   const bool yin = ew > 0 && eh > 0 && y >= ap.edge && y <= ap.edge + eh - 1;
   const uint8_t* M = masks ? masks + (long long)stream * mask_sstride + (long long)y * mask_row_stride : nullptr;
   uint8_t* F = flag + ((long long)stream * ap.h + y) * ap.w;
+  uint8_t v[4];
 #pragma unroll
   for (int b = 0; b < 4; b++) {
     const int x = x0 + b;
-    if (x < ap.w) {
-      uint8_t v = 0;
-      if (yin && x >= ap.edge && x <= ap.edge + ew - 1) v = M ? (uint8_t)(M[x] & 1u) : (uint8_t)1;  // :132 bitwise_and
-      F[x] = v;
-    }
+    v[b] = 0;
+    if (x < ap.w && yin && x >= ap.edge && x <= ap.edge + ew - 1) v[b] = M ? (uint8_t)(M[x] & 1u) : (uint8_t)1;  // :132 bitwise_and
+  }
+  if ((ap.w & 3) == 0) {  // rows of the flag image are dword aligned: one store per quad
+    *reinterpret_cast<unsigned int*>(F + x0) =
+        (unsigned int)v[0] | ((unsigned int)v[1] << 8) | ((unsigned int)v[2] << 16) | ((unsigned int)v[3] << 24);
+  } else {
+#pragma unroll
+    for (int b = 0; b < 4; b++)
+      if (x0 + b < ap.w) F[x0 + b] = v[b];
   }
 }
 
 // Zeroes the cv::circle disc of every in-image feature (:122-131) and resets the per-stream counters.
+// Grid: (chunks of disc rows, streams).
 __global__ __launch_bounds__(256) void anms_disc_kernel(const double2* __restrict__ xy, const int* __restrict__ n,
                                                         int cap, AnmsParams ap, uint8_t* __restrict__ flag,
                                                         unsigned int* __restrict__ cell_max,
                                                         int* __restrict__ cand_cnt) {
-  const int stream = blockIdx.x;
+  const int stream = blockIdx.y;
   const int n0 = n[stream];
   const int rows = 2 * ap.radius + 1;
   uint8_t* F = flag + (long long)stream * ap.h * ap.w;
-  for (int t = threadIdx.x; t < n0 * rows; t += 256) {
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < n0 * rows; t += gridDim.x * 256) {
     const int f = t / rows, dy = t - f * rows - ap.radius;
     const double2 p = xy[(long long)stream * cap + f];
     if (p.x > 0 && p.x < (double)ap.w && p.y > 0 && p.y < (double)ap.h) {  // :123-124
@@ -73,7 +80,7 @@ __global__ __launch_bounds__(256) void anms_disc_kernel(const double2* __restric
       }
     }
   }
-  if (threadIdx.x == 0) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
     cell_max[stream] = 0u;
     cand_cnt[stream] = 0;
   }
@@ -102,19 +109,28 @@ __device__ __forceinline__ unsigned long long anms_key_from_map(const float* __r
 }
 
 // The nfeatures largest candidate keys of a stream, in descending order (= cv's sorted corner list cut
-// at maxCorners).  MSB-first radix select (8 passes of 8 bits) finds the K-th largest key, the keys at
-// or above it are gathered into LDS and sorted there (bitonic, descending).  One block per stream.
-__global__ __launch_bounds__(256) void anms_topk_kernel(const float* __restrict__ lam, long long lam_sstride,
-                                                        const uint8_t* __restrict__ flag,
-                                                        const unsigned int* __restrict__ cell_max,
-                                                        const unsigned long long* __restrict__ cand,
-                                                        const int* __restrict__ cand_cnt, AnmsParams ap,
-                                                        short2* __restrict__ kp, int* __restrict__ ndet) {
+// at maxCorners).  MSB-first radix select (up to 8 passes of 8 bits) finds the K-th largest key, the keys at
+// or above it are gathered into LDS and sorted there (bitonic, descending).  One block per stream, any block
+// size that is a multiple of 64 (the host takes 1024 threads when few streams would otherwise leave the one
+// block of a stream alone with a few hundred thousand keys: C4 with 32 streams, the single-stream host API).
+//   * The first pass also counts the keys.  A pass whose selected bin holds exactly the keys still wanted ends the
+//     search: every key with that prefix belongs to the top K (the K-th lambda is nearly always unique, so the
+//     four passes over the raster-index half of the key are rarely needed).
+//   * Keys are read four per thread and iteration (loads in flight together), and a wave adds the keys that
+//     share the bin of its first lane with ONE LDS atomic: the upper bytes of lambda are the same for most keys
+//     of a frame, and sixteen waves adding one by one to the same address queue behind each other.
+__global__ __launch_bounds__(1024) void anms_topk_kernel(const float* __restrict__ lam, long long lam_sstride,
+                                                         const uint8_t* __restrict__ flag,
+                                                         const unsigned int* __restrict__ cell_max,
+                                                         const unsigned long long* __restrict__ cand,
+                                                         const int* __restrict__ cand_cnt, AnmsParams ap,
+                                                         short2* __restrict__ kp, int* __restrict__ ndet) {
   extern __shared__ __align__(16) uint8_t smem[];
   unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);  // [kcap]
   __shared__ unsigned int s_hist[256];
   __shared__ unsigned long long s_prefix;
-  __shared__ int s_remaining, s_count;
+  __shared__ int s_remaining, s_count, s_stop, s_ncand;
+  const int NT = (int)blockDim.x, tid = (int)threadIdx.x;
   const int stream = blockIdx.x;
   const int total = cand_cnt[stream];
   const bool overflow = total > ap.cand_cap;
@@ -130,65 +146,90 @@ __global__ __launch_bounds__(256) void anms_topk_kernel(const float* __restrict_
     const unsigned long long k = C[i];
     return __uint_as_float((unsigned int)(k >> 32)) > thr ? k : 0ull;
   };
+  // f(key) for every candidate key (0 = none), four independent reads per thread and iteration
+  auto for_keys = [&](auto&& f) {
+    int i = tid;
+    for (; i + 3 * NT < M; i += 4 * NT) {
+      const unsigned long long k0 = key_at(i), k1 = key_at(i + NT), k2 = key_at(i + 2 * NT), k3 = key_at(i + 3 * NT);
+      f(k0);
+      f(k1);
+      f(k2);
+      f(k3);
+    }
+    for (; i < M; i += NT) f(key_at(i));
+  };
+  auto hist_add = [&](unsigned int bin) {  // called by the lanes that hold a key of the current prefix
+    const unsigned int b0 = (unsigned int)__builtin_amdgcn_readfirstlane((int)bin);
+    if (bin == b0) {
+      const unsigned long long m = __ballot(1);
+      if ((int)(threadIdx.x & 63) == __ffsll((long long)m) - 1) atomicAdd(&s_hist[b0], (unsigned int)__popcll(m));
+    } else {
+      atomicAdd(&s_hist[bin], 1u);
+    }
+  };
 
-  // number of candidates (the list length, or a count over the map)
-  if (threadIdx.x == 0) s_count = 0;
-  __syncthreads();
-  {
-    int c = 0;
-    for (int i = threadIdx.x; i < M; i += 256) c += key_at(i) != 0ull;
-    if (c) atomicAdd(&s_count, c);
-  }
-  __syncthreads();
-  const int ncand = s_count;
-  const int K = min(ncand, ap.nfeatures);
   unsigned long long T = 1ull;  // keys are never 0
-  if (ncand > K) {
-    if (threadIdx.x == 0) {
+  int K = 0;
+  {
+    if (tid == 0) {
       s_prefix = 0ull;
-      s_remaining = K;
+      s_stop = 0;
     }
     unsigned long long himask = 0ull;
     for (int b = 7; b >= 0; b--) {
-      s_hist[threadIdx.x] = 0u;
+      for (int i = tid; i < 256; i += NT) s_hist[i] = 0u;
       __syncthreads();
       const unsigned long long prefix = s_prefix;
-      for (int i = threadIdx.x; i < M; i += 256) {
-        const unsigned long long k = key_at(i);
-        if (k != 0ull && (k & himask) == prefix) atomicAdd(&s_hist[(unsigned int)(k >> (8 * b)) & 255u], 1u);
-      }
+      for_keys([&](unsigned long long k) {
+        if (k != 0ull && (k & himask) == prefix) hist_add((unsigned int)(k >> (8 * b)) & 255u);
+      });
       __syncthreads();
-      if (threadIdx.x == 0) {
-        int rem = s_remaining, bin = 255;
-        for (; bin > 0; bin--) {
-          const int hcnt = (int)s_hist[bin];
-          if (hcnt >= rem) break;
-          rem -= hcnt;
+      if (tid == 0) {
+        if (b == 7) {  // the first pass saw every key: the number of candidates
+          int nc = 0;
+          for (int q = 0; q < 256; q++) nc += (int)s_hist[q];
+          s_ncand = nc;
+          s_remaining = min(nc, ap.nfeatures);
+          if (nc <= ap.nfeatures) s_stop = 1;  // every key is kept: T stays 1
         }
-        s_prefix = prefix | ((unsigned long long)bin << (8 * b));
-        s_remaining = rem;
+        if (!s_stop) {
+          int rem = s_remaining, bin = 255;
+          for (; bin > 0; bin--) {
+            const int hcnt = (int)s_hist[bin];
+            if (hcnt >= rem) break;
+            rem -= hcnt;
+          }
+          s_prefix = prefix | ((unsigned long long)bin << (8 * b));
+          s_remaining = rem;
+          // the bin holds exactly the keys still wanted: all keys at or above the prefix are the top K
+          if ((int)s_hist[bin] == rem) s_stop = 2;
+        }
       }
       himask |= 0xffull << (8 * b);
       __syncthreads();
+      if (s_stop) break;
     }
-    T = s_prefix;
+    K = min(s_ncand, ap.nfeatures);
+    if (s_stop != 1) T = s_prefix;
   }
   // gather and sort
   __syncthreads();
-  for (int i = threadIdx.x; i < ap.kcap; i += 256) s_key[i] = 0ull;
-  if (threadIdx.x == 0) s_count = 0;
+  for (int i = tid; i < ap.kcap; i += NT) s_key[i] = 0ull;
+  if (tid == 0) s_count = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < M; i += 256) {
-    const unsigned long long k = key_at(i);
+  for_keys([&](unsigned long long k) {
     if (k != 0ull && k >= T) {
       const int slot = atomicAdd(&s_count, 1);
       if (slot < ap.kcap) s_key[slot] = k;
     }
-  }
+  });
   __syncthreads();
-  for (int size = 2; size <= ap.kcap; size <<= 1)
+  // the slots beyond the gathered keys hold 0 and sort to the end: sort the smallest power of two that holds them
+  int n2 = 1;
+  while (n2 < K) n2 <<= 1;
+  for (int size = 2; size <= n2; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = threadIdx.x; i < ap.kcap / 2; i += 256) {
+      for (int i = tid; i < n2 / 2; i += NT) {
         const int lo = ((i / stride) * stride * 2) + (i % stride), hi = lo + stride;
         const bool desc = ((lo & size) == 0);
         const unsigned long long a = s_key[lo], b2 = s_key[hi];
@@ -200,12 +241,12 @@ __global__ __launch_bounds__(256) void anms_topk_kernel(const float* __restrict_
       __syncthreads();
     }
   short2* out = kp + (long long)stream * ap.kcap;
-  for (int i = threadIdx.x; i < K; i += 256) {
+  for (int i = tid; i < K; i += NT) {
     const int idx = (int)(unsigned int)s_key[i];
     const int y = idx / ap.w;
     out[i] = make_short2((short)(idx - y * ap.w), (short)y);
   }
-  if (threadIdx.x == 0) ndet[stream] = K;
+  if (tid == 0) ndet[stream] = K;
 }
 
 // Position, before libstdc++'s std::sort, of the element std::sort leaves at position p when every
@@ -240,13 +281,13 @@ __device__ __forceinline__ int introsort_equal_src(int n, int p) {
 }
 
 // suppressNonMax + anms::Ssc + the need / detected branches of FeatureDetectorANMS::Detect (:174-186).
-// One block per stream.  The sweep "accept a keypoint iff its cell is uncovered, then cover the cells
+// One block per stream (any multiple of 64 threads up to 1024).  The sweep "accept a keypoint iff its cell is uncovered, then cover the cells
 // within +-2" is sequential in the reference; here only the FIRST keypoint of a cell can ever be
 // accepted, and among those owners the accepted set is the greedy independent set in index order for
 // the relation |d_row| <= 2 && |d_col| <= 2, which is reached by rounds: an owner turns REJECTED when an
 // earlier conflicting owner is ACCEPTED, ACCEPTED when all earlier conflicting owners are REJECTED.
 // Cells: row = floor(y / (w/2)) = (2 y) / w in integers (y, w integers, w >= 1), likewise col.
-__global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict__ kp, const int* __restrict__ ndet,
+__global__ __launch_bounds__(1024) void anms_ssc_kernel(const short2* __restrict__ kp, const int* __restrict__ ndet,
                                                        const int* __restrict__ n_tab, AnmsParams ap,
                                                        double2* __restrict__ sel_xy, int* __restrict__ sel_cnt) {
   // LDS, 17 bytes per keypoint slot (139 KB at 8192): positions, the cell of every keypoint at the current width,
@@ -263,7 +304,8 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
   constexpr unsigned int EMPTY = 0xffffffffu;
   __shared__ int s_low, s_high, s_width, s_prev, s_done, s_nres, s_base;
   __shared__ unsigned int s_kmin, s_kmax;
-  __shared__ int s_wave[4];
+  __shared__ int s_wave[16];
+  const int NT = (int)blockDim.x, NW = NT >> 6;
   const int stream = blockIdx.x;
   const int n = ndet[stream];
   int need = ap.max_features - n_tab[stream];  // :174-175
@@ -271,7 +313,7 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
   const short2* K = kp + (long long)stream * ap.kcap;
   double2* out = sel_xy + (long long)stream * ap.kcap;
   if (need >= n) {  // :184-186 every detected keypoint, in GFTT order
-    for (int i = threadIdx.x; i < n; i += 256) out[i] = make_double2((double)K[i].x, (double)K[i].y);
+    for (int i = threadIdx.x; i < n; i += NT) out[i] = make_double2((double)K[i].x, (double)K[i].y);
     if (threadIdx.x == 0) sel_cnt[stream] = n;
     return;
   }
@@ -280,7 +322,7 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
     return;
   }
   // NonMaximumSuppression.cpp:43-53: responses truncate to int 0, cv::sortIdx DESCENDING = reversed std::sort
-  for (int i = threadIdx.x; i < n; i += 256) {
+  for (int i = threadIdx.x; i < n; i += NT) {
     const short2 p = K[introsort_equal_src(n, n - 1 - i)];
     sx[i] = p.x;
     sy[i] = p.y;
@@ -315,8 +357,15 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
     __syncthreads();
     if (s_done) break;
     const int width = s_width;
-    for (int i = threadIdx.x; i < ap.hash_size; i += 256) hown[i] = EMPTY;
-    for (int i = threadIdx.x; i < n; i += 256) {
+    // The widths the search visits are mostly large: the whole cell grid then fits the table and a cell's slot is
+    // its raster index (no probing, no key compare: the neighbourhood test of the rounds is 24 plain reads);
+    // small widths hash the occupied cells.
+    const unsigned int nrow = (unsigned int)(2 * (ap.h - 1)) / (unsigned int)width + 1u;
+    const unsigned int ncol = (unsigned int)(2 * (ap.w - 1)) / (unsigned int)width + 1u;
+    const bool dense = (unsigned long long)nrow * ncol <= (unsigned long long)ap.hash_size;
+    const int nslot = dense ? (int)(nrow * ncol) : ap.hash_size;
+    for (int i = threadIdx.x; i < nslot; i += NT) hown[i] = EMPTY;
+    for (int i = threadIdx.x; i < n; i += NT) {
       const unsigned int row = (unsigned int)(2 * (int)sy[i]) / (unsigned int)width;
       const unsigned int col = (unsigned int)(2 * (int)sx[i]) / (unsigned int)width;
       cell[i] = (row << 16) | col;
@@ -339,6 +388,10 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
       }
     };
     auto owner_of = [&](unsigned int key) -> unsigned int {
+      if (dense) {
+        const unsigned int row = key >> 16, col = key & 0xffffu;
+        return (row < nrow && col < ncol) ? hown[row * ncol + col] : EMPTY;
+      }
       unsigned int h = (key * 2654435761u) >> (32 - ap.hash_bits);
       for (;;) {
         const unsigned int e = hown[h];
@@ -347,44 +400,88 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
         h = (h + 1) & (unsigned int)(ap.hash_size - 1);
       }
     };
-    for (int i = threadIdx.x; i < n; i += 256) (void)find_or_claim(cell[i], (unsigned int)i);
+    if (dense) {
+      for (int i = threadIdx.x; i < n; i += NT) atomicMin(&hown[(cell[i] >> 16) * ncol + (cell[i] & 0xffffu)], (unsigned int)i);
+    } else {
+      for (int i = threadIdx.x; i < n; i += NT) (void)find_or_claim(cell[i], (unsigned int)i);
+    }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) state[i] = (owner_of(cell[i]) == (unsigned int)i) ? 0 : 2;  // 0 U, 1 A, 2 R
+    for (int i = threadIdx.x; i < n; i += NT) state[i] = (owner_of(cell[i]) == (unsigned int)i) ? 0 : 2;  // 0 U, 1 A, 2 R
     __syncthreads();
     for (;;) {
       int undecided = 0;
-      for (int i = threadIdx.x; i < n; i += 256) {
-        if (state[i] != 0) continue;
-        const int row = (int)(cell[i] >> 16), col = (int)(cell[i] & 0xffffu);
-        bool rejected = false, blocked = false;
-        for (int dr = -2; dr <= 2 && !rejected; dr++)
-          for (int dc = -2; dc <= 2; dc++) {
-            if (dr == 0 && dc == 0) continue;
-            const int rr = row + dr, cc = col + dc;
-            if (rr < 0 || cc < 0) continue;
-            const unsigned int j = owner_of(((unsigned int)rr << 16) | (unsigned int)cc);
-            if (j < (unsigned int)i) {
-              const uint8_t st = state[j];
-              if (st == 1) {
-                rejected = true;
-                break;
+      if (dense) {
+        // the 24 neighbour slots are plain addresses: read all owners, then all their states, then decide (one
+        // probe after the other -- owner, state, branch -- an undecided owner waited for 48 dependent LDS reads a
+        // round, and with a fine grid nearly every keypoint owns its cell).  A state read here is at least as new
+        // as the last barrier, which is all the rounds need.
+        const uint8_t* st_r = const_cast<const uint8_t*>(state);
+        for (int i = threadIdx.x; i < n; i += NT) {
+          if (st_r[i] != 0) continue;
+          const int row = (int)(cell[i] >> 16), col = (int)(cell[i] & 0xffffu);
+          unsigned int own[24];
+          {
+            int q = 0;
+#pragma unroll
+            for (int dr = -2; dr <= 2; dr++)
+#pragma unroll
+              for (int dc = -2; dc <= 2; dc++) {
+                if (dr == 0 && dc == 0) continue;
+                const int rr = row + dr, cc = col + dc;
+                const bool in = (unsigned int)rr < nrow && (unsigned int)cc < ncol;
+                const unsigned int o = hown[in ? rr * (int)ncol + cc : 0];
+                own[q++] = in ? o : EMPTY;
               }
-              if (st == 0) blocked = true;
-            }
           }
-        if (rejected)
-          state[i] = 2;
-        else if (!blocked)
-          state[i] = 1;
-        else
-          undecided = 1;
+          bool rejected = false, blocked = false;
+#pragma unroll
+          for (int q = 0; q < 24; q++) {
+            const bool earlier = own[q] < (unsigned int)i;
+            const uint8_t st = st_r[earlier ? own[q] : (unsigned int)i];
+            rejected |= earlier && st == 1;
+            blocked |= earlier && st == 0;
+          }
+          if (rejected)
+            state[i] = 2;
+          else if (!blocked)
+            state[i] = 1;
+          else
+            undecided = 1;
+        }
+      } else {
+        for (int i = threadIdx.x; i < n; i += NT) {
+          if (state[i] != 0) continue;
+          const int row = (int)(cell[i] >> 16), col = (int)(cell[i] & 0xffffu);
+          bool rejected = false, blocked = false;
+          for (int dr = -2; dr <= 2 && !rejected; dr++)
+            for (int dc = -2; dc <= 2; dc++) {
+              if (dr == 0 && dc == 0) continue;
+              const int rr = row + dr, cc = col + dc;
+              if (rr < 0 || cc < 0) continue;
+              const unsigned int j = owner_of(((unsigned int)rr << 16) | (unsigned int)cc);
+              if (j < (unsigned int)i) {
+                const uint8_t st = state[j];
+                if (st == 1) {
+                  rejected = true;
+                  break;
+                }
+                if (st == 0) blocked = true;
+              }
+            }
+          if (rejected)
+            state[i] = 2;
+          else if (!blocked)
+            state[i] = 1;
+          else
+            undecided = 1;
+        }
       }
       if (!__syncthreads_or(undecided)) break;
     }
     // result = accepted keypoints in sweep order
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
-    for (int c0 = 0; c0 < n; c0 += 256) {
+    for (int c0 = 0; c0 < n; c0 += NT) {
       const int i = c0 + threadIdx.x;
       const bool acc = (i < n) && state[i] == 1;
       const unsigned long long bal = __ballot(acc);
@@ -395,7 +492,11 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
       off += __popcll(bal & ((1ull << lane) - 1ull));
       if (acc) res[off] = (unsigned short)i;
       __syncthreads();
-      if (threadIdx.x == 0) s_base += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+      if (threadIdx.x == 0) {
+        int t = 0;
+        for (int q = 0; q < NW; q++) t += s_wave[q];
+        s_base += t;
+      }
       __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -413,7 +514,7 @@ __global__ __launch_bounds__(256) void anms_ssc_kernel(const short2* __restrict_
     if (s_done) break;
   }
   const int nres = s_nres;
-  for (int k = threadIdx.x; k < nres; k += 256) out[k] = make_double2((double)sx[res[k]], (double)sy[res[k]]);
+  for (int k = threadIdx.x; k < nres; k += NT) out[k] = make_double2((double)sx[res[k]], (double)sy[res[k]]);
   if (threadIdx.x == 0) sel_cnt[stream] = nres;
 }
 

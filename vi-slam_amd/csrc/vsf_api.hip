@@ -511,8 +511,10 @@ int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long l
     ProfScope prof(c, VSF_K_OCCUPANCY, s);
     hipLaunchKernelGGL(anms_mask_kernel, dim3((W + 1023) / 1024, H, streams), dim3(256), 0, s, masks, mask_sstride,
                        mask_pitch, ap, c->d_aflag);
-    hipLaunchKernelGGL(anms_disc_kernel, dim3(streams), dim3(256), 0, s, c->d_xy, c->d_n, c->cap, ap, c->d_aflag,
-                       c->d_cellmax, c->d_candcnt);
+    int chunks = (c->cap * (2 * ap.radius + 1) + 1023) / 1024;  // four disc rows per thread at a full table
+    chunks = chunks < 1 ? 1 : (chunks > 64 ? 64 : chunks);
+    hipLaunchKernelGGL(anms_disc_kernel, dim3(chunks, streams), dim3(256), 0, s, c->d_xy, c->d_n, c->cap, ap,
+                       c->d_aflag, c->d_cellmax, c->d_candcnt);
   }
   const int tiles_x = sc_tiles(W, SC_IW), tiles_y = sc_tiles(H, SC_IH);
   const long long fsz = (long long)W * H;
@@ -540,10 +542,13 @@ int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long l
   }
   {
     ProfScope prof(c, VSF_K_SELECT, s);
-    hipLaunchKernelGGL(anms_topk_kernel, dim3(streams), dim3(256), (size_t)ap.kcap * 8, s, c->d_lam,
+    // one workgroup per stream in both kernels: few streams get large workgroups (a stream's few hundred thousand
+    // keys behind 256 threads took 3.6 of C4 + ANMS's 10.6 ms per 32 frames), many streams fill the chip anyway
+    const int nt = streams >= 1024 ? 256 : (streams >= 512 ? 512 : 1024);
+    hipLaunchKernelGGL(anms_topk_kernel, dim3(streams), dim3(nt), (size_t)ap.kcap * 8, s, c->d_lam,
                        (long long)c->lam_total, c->d_aflag, c->d_cellmax, c->d_acand, c->d_candcnt, ap, c->d_akp,
                        c->d_andet);
-    hipLaunchKernelGGL(anms_ssc_kernel, dim3(streams), dim3(256), (size_t)anms_ssc_smem(ap), s, c->d_akp, c->d_andet,
+    hipLaunchKernelGGL(anms_ssc_kernel, dim3(streams), dim3(nt), (size_t)anms_ssc_smem(ap), s, c->d_akp, c->d_andet,
                        c->d_n, ap, c->d_aselxy, c->d_aselcnt);
   }
   {
