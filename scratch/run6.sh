@@ -23,3 +23,7 @@ import json,sys
 d=json.load(open('$out/${tag}_bench_$f.json'))
 print('$f', round(d['value']), 'frames/s', round(d['ms_per_step'],3),'ms', 'verified', round(d['config']['verified_fraction'],4), 'lk', round(d['kernel_ms']['lk'],3), 'score', round(d['kernel_ms']['score'],3), 'frac', round(d['roofline']['frac'],4), 'cpu', d.get('cpu_baseline',{}).get('value'), d.get('cpu_baseline',{}).get('single_thread',{}).get('value'))
 "; done
+# per-kernel stats of the two ANMS lines
+bash scratch/run21.sh || exit 1
+cp $out/prof_c4a_kernel_stats.csv $out/${tag}_kernel_stats_C4_anms.csv
+cp $out/prof_c2a_kernel_stats.csv $out/${tag}_kernel_stats_anms_lssd.csv
