@@ -405,7 +405,7 @@ __device__ __forceinline__ float float_order_decode(unsigned int e) {
 //     reflects at the CELL border and sums in double like cv::boxFilter does for 32F input.
 constexpr int SC_TW = 64, SC_TH = 16;          // lambda block of a tile
 constexpr int SC_IW = SC_TW - 2, SC_IH = SC_TH - 2;  // candidate positions of a tile (tile step)
-constexpr int SC_FP = 76;  // LDS pitch (floats) of the staged tile (tile width + up to 3 pixels of dword alignment)
+constexpr int SC_FP = 72;  // LDS pitch (floats) of the staged tile (tile width + up to 3 pixels of dword alignment, rounded up to dwords)
 constexpr int SC_LP = SC_TW + 1;               // LDS pitch of the lambda block
 constexpr int SC_LCAP = SC_IH * SC_IW / 4 + 64;  // keys gathered in LDS per block; beyond it they go straight to the list
 
@@ -433,7 +433,8 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   static_assert(4 * NDW <= SC_FP && SC_FP % 4 == 0, "tile pitch");
   // LDS: the staged image (as float32: every pixel is converted once, not once per use) is dead once the
   // covariance products exist, and those once lambda exists; the lambda block and the mask bits reuse the
-  // image's space, the gathered keys the products'.  20 KB a block, 7 blocks per CU.  (The products stay
+  // image's space, the gathered keys the products'.  20.0 KB a block with the 3x3 box (8 blocks per CU), 22.9 KB with
+  // the 4x4 box (7: LDS is granted in 1280-byte units, and a row pitch of 76 floats was one unit too many).  (The products stay
   // float32 although the box filter sums them in double: held as float64 the conversions drop to a third,
   // but the 8-byte LDS reads of the box stage then cost more than the conversions saved -- the LDS pipe is
   // nearly as busy as the VALU here -- and the kernel ran 1.7x slower.)
@@ -740,7 +741,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
 // blocks queue on one address (the L2's same-address atomic rate: 1.67 against 1.30 ms per 1024 frames, measured on
 // the former separate candidates kernel).
 template <int BS>
-__global__ __launch_bounds__(256) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
+__global__ __launch_bounds__(256, (BS == 4 ? 7 : 8)) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
                                                     int row_stride, int w, int h,
                                                     const uint8_t* __restrict__ masks, long long mask_sstride,
                                                     int mask_row_stride, GridView G,
