@@ -450,8 +450,9 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
   const int W = c->p.width, H = c->p.height;
   {
     ProfScope prof(c, VSF_K_OCCUPANCY, s);
-    const size_t sm = (size_t)(c->hash_size + c->ncell) * sizeof(int);
-    hipLaunchKernelGGL(occupancy_kernel, dim3(streams), dim3(256), sm, s, c->d_xy, c->d_n, c->cap, G, W, H,
+    const size_t sm = (size_t)(c->hash_size + c->ncell + 2 * (G.cols + G.rows)) * sizeof(int);
+    const int nt = streams >= 1024 ? 256 : (streams >= 512 ? 512 : 1024);
+    hipLaunchKernelGGL(occupancy_kernel, dim3(streams), dim3(nt), sm, s, c->d_xy, c->d_n, c->cap, G, W, H,
                        c->hash_size, c->d_need, c->d_nact, c->d_cellmax, c->d_candcnt);
   }
   const int tiles_x = sc_tiles(c->max_cw, SC_IW), tiles_y = sc_tiles(c->max_ch, SC_IH);
@@ -874,7 +875,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   }
   c->hash_size = 64;
   while (c->hash_size < 2 * c->cap) c->hash_size <<= 1;
-  if ((size_t)(c->hash_size + c->ncell) * 4 > 150 * 1024) {
+  if ((size_t)(c->hash_size + c->ncell + 2 * (p->grid_cols + p->grid_rows)) * 4 > 150 * 1024) {
     delete c;
     return VSF_E_INVALID;
   }
@@ -1034,7 +1035,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     acc(hipMemcpy(c->d_lam_off, lam_off.data(), lam_off.size() * sizeof(int), hipMemcpyHostToDevice));
     // dynamic LDS above the default limit needs an explicit opt-in; the attribute belongs to the kernel, not to
     // the context, so only ever raise it (an earlier, larger context still launches with its own size)
-    const int occ_sm = (c->hash_size + c->ncell) * 4;
+    const int occ_sm = (c->hash_size + c->ncell + 2 * (c->p.grid_cols + c->p.grid_rows)) * 4;
     const int sel_sm = c->cand_cap * 8 + (c->grid_max > 0 ? c->grid_max : 1) * 12;
     int app_sm = (c->ncell + 1 + c->ncell * (c->grid_max > 0 ? c->grid_max : 1)) * 4;
     if (use_anms && (2 + c->anms.kcap) * 4 > app_sm) app_sm = (2 + c->anms.kcap) * 4;

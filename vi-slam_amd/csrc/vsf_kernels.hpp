@@ -318,9 +318,11 @@ struct GridView {
 };
 
 // Occupancy (Q4): number of distinct flagged pixels per cell, need per cell, and the number of
-// cells processed before the reference's early `break` (Q2).  One block per stream; an LDS hash
-// set de-duplicates pixels exactly like the reference's flag image.
-__global__ __launch_bounds__(256) void occupancy_kernel(const double2* __restrict__ xy, const int* __restrict__ n,
+// cells processed before the reference's early `break` (Q2).  One block per stream (any multiple of 64 threads:
+// the host takes 1024 when few streams would leave a stream's thousands of features to 256 threads); an LDS hash
+// set de-duplicates pixels exactly like the reference's flag image.  LDS: hash | per-cell counts | column and row
+// intervals of the grid.
+__global__ __launch_bounds__(1024) void occupancy_kernel(const double2* __restrict__ xy, const int* __restrict__ n,
                                                         int cap, GridView G, int w, int h, int hash_size,
                                                         int* __restrict__ need, int* __restrict__ n_active,
                                                         unsigned int* __restrict__ cell_max,
@@ -328,12 +330,25 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const double2* __restric
   extern __shared__ __align__(16) uint8_t smem[];
   int* s_hash = reinterpret_cast<int*>(smem);
   int* s_cnt = s_hash + hash_size;
+  int* s_col = s_cnt + G.ncell;    // [cols][2] x0, x1 (exclusive)
+  int* s_row = s_col + 2 * G.cols;  // [rows][2] y0, y1
+  const int NT = (int)blockDim.x;
   const int stream = blockIdx.x;
   const int n0 = n[stream];
-  for (int i = threadIdx.x; i < hash_size; i += 256) s_hash[i] = -1;
-  for (int i = threadIdx.x; i < G.ncell; i += 256) s_cnt[i] = 0;
+  for (int i = threadIdx.x; i < hash_size; i += NT) s_hash[i] = -1;
+  for (int i = threadIdx.x; i < G.ncell; i += NT) s_cnt[i] = 0;
+  for (int i = threadIdx.x; i < G.cols; i += NT) {
+    const int4 r = G.rects[i * G.rows];
+    s_col[2 * i] = r.x;
+    s_col[2 * i + 1] = r.x + r.z;
+  }
+  for (int i = threadIdx.x; i < G.rows; i += NT) {
+    const int4 r = G.rects[i];
+    s_row[2 * i] = r.y;
+    s_row[2 * i + 1] = r.y + r.w;
+  }
   __syncthreads();
-  for (int i = threadIdx.x; i < n0; i += 256) {
+  for (int i = threadIdx.x; i < n0; i += NT) {
     const double2 p = xy[(long long)stream * cap + i];
     if (p.x > 0 && p.x < (double)w && p.y > 0 && p.y < (double)h) {  // :123-124 strict, in double
       const int ix = (int)p.x, iy = (int)p.y;                        // :125 at<uint8_t>(pos[1], pos[0])
@@ -353,11 +368,9 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const double2* __restric
         // GenerateGrid's cells are a product of column intervals and row intervals (cell = column * rows + row; the
         // rounded intervals may overlap or leave gaps, Q1): test cols + rows intervals, not cols * rows rectangles
         for (int cx = 0; cx < G.cols; cx++) {
-          const int4 rx = G.rects[cx * G.rows];
-          if (ix >= rx.x && ix < rx.x + rx.z) {
+          if (ix >= s_col[2 * cx] && ix < s_col[2 * cx + 1]) {
             for (int cy = 0; cy < G.rows; cy++) {
-              const int4 ry = G.rects[cy];
-              if (iy >= ry.y && iy < ry.y + ry.w) atomicAdd(&s_cnt[cx * G.rows + cy], 1);
+              if (iy >= s_row[2 * cy] && iy < s_row[2 * cy + 1]) atomicAdd(&s_cnt[cx * G.rows + cy], 1);
             }
           }
         }
@@ -374,7 +387,7 @@ __global__ __launch_bounds__(256) void occupancy_kernel(const double2* __restric
     }
     n_active[stream] = act;
   }
-  for (int c = threadIdx.x; c < G.ncell; c += 256) {
+  for (int c = threadIdx.x; c < G.ncell; c += NT) {
     cell_max[stream * G.ncell + c] = 0u;
     cand_cnt[stream * G.ncell + c] = 0;
   }
