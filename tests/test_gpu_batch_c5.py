@@ -203,6 +203,8 @@ def test_template_cache_invalidation(vsf, oracle, synth):
     ("C2", 752, 480, C2_DET, C2_TRK, 1024, 8, 4),
     ("C3", 1280, 720, (5, 8, 1000, 8.0), (30, 0.01, 21, 3, 1.0), 256, 4, 3),
     ("C4", 3840, 2160, (10, 16, 4000, 12.0), (30, 0.01, 21, 4, 1.0), 32, 2, 3),
+    # 512 streams: the middle workgroup size of the per-stream kernels (1024 threads below 512 streams, 256 from 1024)
+    ("512 streams", 320, 240, (3, 4, 120, 8.0), (30, 0.01, 15, 2, 1.0), 512, 4, 4),
 ])
 def test_full_size_batch_by_replication(vsf, oracle, synth, name, w, h, det, trk, B, D, T):
     """BASELINE configs[1..3] at FULL size (the bench's batches: 1024 streams of 752x480, 256 of 1280x720, 32 of
