@@ -32,8 +32,9 @@ extern "C" {
 #define VSF_E_INVALID (-1)   /* bad argument / parameter out of the supported range */
 #define VSF_E_HIP (-2)       /* a HIP runtime call failed (see vsf_last_error) */
 #define VSF_E_CAPACITY (-3)  /* feature table capacity exhausted */
-#define VSF_E_GEOMETRY (-4)  /* frame size differs from the context's, or a grid cell leaves the image
-                                (cv::Mat::operator()(Rect) would throw in the reference) */
+#define VSF_E_GEOMETRY (-4)  /* a grid cell leaves the image (cv::Mat::operator()(Rect) would throw in the reference);
+                                a frame whose size differs from the stored previous frame's (cv::calcOpticalFlowPyrLK
+                                would throw); a frame size a batched context was not created for */
 #define VSF_E_NOMEM (-5)
 
 typedef struct vsf_ctx vsf_ctx;
@@ -80,6 +81,13 @@ typedef struct vsf_params {
   int32_t lssd_levels;             /* optical_flow_levels_ 3 (images 0..levels); <= 7 */
   int32_t lssd_max_iterations;     /* optical_flow_max_iterations_ 5 */
   double lssd_max_recovered_dist;  /* optical_flow_max_recovered_dist_ 0.09, compared with the SQUARED distance */
+  /* LK template cache (an optimisation of this library, no counterpart in the reference; results are bit-identical
+   * with and without it): 2 x streams x capacity x levels x 2576 bytes of device memory (6.3 GB at 1024 streams of
+   * 752x480 / 300 features, 6 MB for one stream), allocated by vsf_create after everything else.  0 = allocate it
+   * when it stays below 16 GiB; > 0 = that many bytes at most; < 0 = never.  When a later allocation of the context
+   * (the host-pointer API's staging, the frame-pair buffers) does not fit, the cache is given back first.
+   * vsf_get_info reports what the context holds. */
+  int64_t lk_cache_max_bytes;
 } vsf_params;
 
 #define VSF_TRACKER_LK 0
@@ -93,6 +101,15 @@ typedef struct vsf_track_stats {
   int32_t input, forward, backward, verified;
 } vsf_track_stats;
 
+/* What a context holds (vsf_get_info). */
+typedef struct vsf_info {
+  int64_t lk_cache_bytes; /* device bytes of the LK template cache; 0 = not held (disabled, too large, given back) */
+  int32_t width, height;  /* current frame size (the host-pointer API may have re-created the context's buffers) */
+  int32_t streams, capacity;
+  int32_t levels;         /* effective pyramid levels (maxLevel + 1 after cv's window rule) */
+  int32_t reserved;
+} vsf_info;
+
 /* Fills *p with the reference's example parameters (example_feature_detection_and_tracking.cpp:19-23
  * grid 4x4 / 300 features, OpenCV's 21x21 window, 4 levels, 30 iterations, eps 0.01) at 752x480. */
 void vsf_default_params(vsf_params* p);
@@ -101,6 +118,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out);
 void vsf_destroy(vsf_ctx* ctx);
 const char* vsf_last_error(const vsf_ctx* ctx);
 const char* vsf_version(void);
+int vsf_get_info(const vsf_ctx* ctx, vsf_info* out);
 
 /* ---- single-stream host-pointer API: the drop-in for the reference interfaces (uses stream 0) ---- */
 
@@ -119,10 +137,28 @@ int vsf_track_pair(vsf_ctx* ctx, const uint8_t* prev, int32_t prev_stride, const
 /* FeatureDetectorShiTomasiBucketing::UpdateDetection (FeatureDetectorShiTomasiBucketing.cpp:50-239)
  * including its quirks (column-major cells, early break, id counter), without
  * the cv::imshow side effect.  mask may be NULL (no mask); non-zero = allowed.  `capacity` is the
- * length of the caller's arrays. */
+ * length of the caller's arrays: it must hold what the call can produce, min(context capacity, n + rows * cols *
+ * (max_features / (rows * cols))) entries (n + anms_detection_features for the ANMS detector); a shorter array is
+ * refused with VSF_E_CAPACITY BEFORE anything runs, so the call can be repeated (vsf_step likewise). */
 int vsf_detect(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride,
                const uint8_t* mask, int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age,
                int32_t* n_inout, int32_t capacity);
+
+/* UpdateDetection on a multi-channel frame: the reference converts any frame with channels() != 1 by
+ * cv::cvtColor(CV_BGR2GRAY) first (FeatureDetectorShiTomasiBucketing.cpp:105-110, FeatureDetectorANMS.cpp:98-99).
+ * img holds `channels` = 3 (BGR) or 4 (BGRA) interleaved bytes per pixel, rows `stride` bytes apart; the conversion
+ * (cv's fixed-point weights, (1868 B + 9617 G + 4899 R + 2^13) >> 14) runs on the device.  Otherwise vsf_detect. */
+int vsf_detect_bgr(vsf_ctx* ctx, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t channels,
+                   const uint8_t* mask, int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age,
+                   int32_t* n_inout, int32_t capacity);
+
+/* Frame size per call.  The reference interfaces take any cv::Mat per call; a context is created for one size
+ * (vsf_params.width / height) and, when it holds ONE stream, follows the caller: vsf_detect, vsf_detect_bgr,
+ * vsf_track_pair, and vsf_track / vsf_step while no previous frame is stored, re-create the context's device
+ * buffers for a frame of another size (about a millisecond; max_feature_index_ is kept, the previous frame and the
+ * LK template cache are not).  vsf_track / vsf_step with a stored previous frame of another size return
+ * VSF_E_GEOMETRY, where cv::calcOpticalFlowPyrLK throws; so does a grid that does not fit the new size, and any
+ * size change on a context of several streams. */
 
 /* Track, then UpdateDetection on the SAME frame -- the loop body of the reference's example
  * (example/vslam/example_feature_detection_and_tracking.cpp:43-55) -- as one call: the frame crosses PCIe once, the
@@ -149,6 +185,11 @@ int vsf_batch_track(vsf_ctx* ctx, const uint8_t* d_frames, int64_t frame_stride_
 int vsf_batch_detect(vsf_ctx* ctx, const uint8_t* d_frames, int64_t frame_stride_bytes,
                      int32_t row_stride, const uint8_t* d_masks, int64_t mask_stride_bytes,
                      int32_t mask_row_stride, void* hip_stream);
+/* cv::cvtColor(CV_BGR2GRAY) of `streams` device-resident multi-channel frames (3 or 4 interleaved bytes per pixel,
+ * B first) into 8-bit frames the batched calls take; one kernel on hip_stream. */
+int vsf_batch_bgr_to_gray(vsf_ctx* ctx, const uint8_t* d_bgr, int64_t bgr_frame_stride_bytes, int32_t bgr_row_stride,
+                          int32_t channels, uint8_t* d_gray, int64_t gray_frame_stride_bytes, int32_t gray_row_stride,
+                          void* hip_stream);
 /* One frontend step per stream: Track, then UpdateDetection on the same frame. */
 int vsf_batch_step(vsf_ctx* ctx, const uint8_t* d_frames, int64_t frame_stride_bytes,
                    int32_t row_stride, void* hip_stream);
@@ -167,6 +208,27 @@ int vsf_batch_device_tables(vsf_ctx* ctx, void** ids, void** xy, void** age, voi
  * [streams][capacity] in the caller's device buffer (streams*capacity*24 bytes), padded with
  * valid = 0, for the RCCL gather of tracks.  Enqueues one kernel on hip_stream. */
 int vsf_batch_export_tracks(vsf_ctx* ctx, void* d_records, void* hip_stream);
+/* ---- multi-GPU: one process per GPU, streams sharded over the ranks, no data-path collective.
+ * The one exchange is an all-gather of the 24-byte track records over RCCL / xGMI.  No counterpart in the
+ * reference (single process, single device; its loop is example/vslam/example_serialization.cpp:159-171): this is
+ * what a C++ host running that loop on one GPU per process adds to see every rank's tracks.
+ * librccl is opened at run time (dlopen), so single-GPU users need not have it.
+ *   rank 0: vsf_comm_unique_id(id), hand the VSF_COMM_ID_BYTES bytes to the other ranks by any means (file, socket,
+ *   MPI); every rank: vsf_comm_create(id, rank, nranks, device, &comm) -- collective, like ncclCommInitRank;
+ *   or vsf_comm_wrap() around an ncclComm_t the host already has.  nranks == 1 needs neither id nor librccl. */
+#define VSF_COMM_ID_BYTES 128
+typedef struct vsf_comm vsf_comm;
+int vsf_comm_unique_id(uint8_t* id /* [VSF_COMM_ID_BYTES] */);
+int vsf_comm_create(const uint8_t* id, int32_t rank, int32_t nranks, int32_t device_id, vsf_comm** out);
+int vsf_comm_wrap(void* nccl_comm /* ncclComm_t */, int32_t device_id, vsf_comm** out);
+void vsf_comm_destroy(vsf_comm* comm);
+int vsf_comm_rank(const vsf_comm* comm, int32_t* rank, int32_t* nranks);
+const char* vsf_comm_last_error(void);
+/* vsf_batch_export_tracks of this rank into slot `rank` of d_recv, then ncclAllGather in place: afterwards d_recv
+ * holds nranks x streams x capacity records, rank-major, on every rank (every rank's context must have the same
+ * streams and capacity).  Enqueues on hip_stream, does not synchronise.  comm == NULL: a world of one (export only). */
+int vsf_gather_tracks(vsf_ctx* ctx, vsf_comm* comm, void* d_recv, void* hip_stream);
+
 /* Sticky per-stream device status of the batched calls: 0 or VSF_E_CAPACITY.  Synchronous. */
 int vsf_batch_status(vsf_ctx* ctx, int32_t* status /* [streams] */);
 /* Forget the previous frame (next vsf_batch_track / vsf_track only stores its frame). */
@@ -256,6 +318,11 @@ int vsf_lk_points_noalloc(const vsf_params* p, const uint8_t* d_prev, int32_t pr
 #define VSF_K_APPEND 7
 #define VSF_K_COUNT 8
 int vsf_profile_enable(vsf_ctx* ctx, int32_t on);
+/* Diagnostic: the shader clock the GPU holds right now.  A one-lane kernel on a stream of its own spins for spin_us
+ * microseconds of the constant-rate counter (s_memrealtime) and reports the advance of the shader cycle counter
+ * (s_memtime) over it; called while a step's kernels are queued on another stream it measures the clock under that
+ * load.  Blocks for spin_us; allocates 32 bytes.  realtime_mhz (may be NULL) = the constant counter's rate. */
+int vsf_debug_sclk_probe(vsf_ctx* ctx, int32_t spin_us, double* sclk_mhz, double* realtime_mhz);
 /* Sums the recorded event pairs: total milliseconds and launch count per kernel id.  Synchronous;
  * clears the record. */
 int vsf_profile_read(vsf_ctx* ctx, float* total_ms /* [VSF_K_COUNT] */,

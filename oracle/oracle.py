@@ -148,6 +148,16 @@ def good_features_to_track(img, max_corners, quality, min_dist, roi=None, mask=N
     return out[:n].copy()
 
 
+def bgr2gray(img):
+    """cv::cvtColor(img, CV_BGR2GRAY) of an [h][w][3 or 4] uint8 array."""
+    img = np.ascontiguousarray(img, np.uint8)
+    assert img.ndim == 3 and img.shape[2] in (3, 4)
+    h, w, cn = img.shape
+    out = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray(img.ctypes.data_as(C.c_void_p), w, h, w * cn, cn, out.ctypes.data_as(C.c_void_p), w)
+    return out
+
+
 def generate_grid(w, h, cols, rows):
     rects = np.zeros((cols * rows, 4), np.int32)
     origin = np.zeros((cols * rows, 2), np.float32)

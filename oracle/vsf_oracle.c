@@ -562,6 +562,16 @@ void orc_detector_init(orc_detector* d, int32_t rows, int32_t cols, int32_t max_
 /* ref: FeatureDetectorShiTomasiBucketing.cpp:13-36 (GenerateGrid, column-major, Rect2f) and
  * :144-149 (Rect2f -> Rect conversion = cv::saturate_cast<int>(float) = cvRound on x, y, width,
  * height independently).  Returns the number of cells. */
+void orc_bgr2gray(const uint8_t* src, int w, int h, int stride, int cn, uint8_t* dst, int dst_stride) {
+  /* cv RGB2Gray<uchar>: tab[b] + tab[g + 256] + tab[r + 512] with the rounding constant folded into the r table */
+  for (int y = 0; y < h; y++) {
+    const uint8_t* s = src + (size_t)y * stride;
+    uint8_t* d = dst + (size_t)y * dst_stride;
+    for (int x = 0; x < w; x++, s += cn)
+      d[x] = (uint8_t)((s[0] * 1868 + s[1] * 9617 + s[2] * 4899 + (1 << 13)) >> 14);
+  }
+}
+
 int orc_generate_grid(int w, int h, int cols, int rows, int* rects, float* origin) {
   const double dx = (double)w / (double)cols, dy = (double)h / (double)rows;
   int k = 0;

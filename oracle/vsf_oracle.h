@@ -82,6 +82,12 @@ typedef struct {
 
 void orc_detector_init(orc_detector* d, int32_t rows, int32_t cols, int32_t max_features,
                        double min_distance);
+/* cv::cvtColor(src, dst, CV_BGR2GRAY) for 8-bit input of cn = 3 or 4 interleaved channels, B first: what the
+ * detectors do to a multi-channel frame (FeatureDetectorShiTomasiBucketing.cpp:105-110, FeatureDetectorANMS.cpp:
+ * 98-99).  OpenCV 3.4 imgproc/color_rgb.cpp RGB2Gray<uchar>: fixed-point weights B2Y = 1868, G2Y = 9617,
+ * R2Y = 4899, yuv_shift = 14, rounding constant 1 << 13 (recalled; parity unpinned like the rest of the OpenCV
+ * arithmetic -- an IPP build may round differently). */
+void orc_bgr2gray(const uint8_t* src, int w, int h, int stride, int cn, uint8_t* dst, int dst_stride);
 int orc_generate_grid(int w, int h, int cols, int rows, int* rects /* 4*cells: x,y,w,h */,
                       float* origin /* 2*cells Rect2f x,y; may be NULL */);
 int orc_detector_update(orc_detector* d, const uint8_t* img, int w, int h, int stride,

@@ -36,11 +36,27 @@ def test_params_struct_layout(vsf):
     with tempfile.TemporaryDirectory() as d:
         src = os.path.join(d, "sz.c")
         open(src, "w").write('#include <stdio.h>\n#include "vsf.h"\nint main(void){printf("%zu %zu\\n",'
-                             'sizeof(vsf_params),sizeof(vsf_track_stats));return 0;}\n')
+                             'sizeof(vsf_params),sizeof(vsf_track_stats));printf("%zu %d\\n",sizeof(vsf_info),'
+                             'VSF_COMM_ID_BYTES);return 0;}\n')
         exe = os.path.join(d, "sz")
         subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
-        a, b = subprocess.check_output([exe]).split()
+        a, b, c, d = subprocess.check_output([exe]).split()
     assert int(a) == C.sizeof(vsf.VsfParams) and int(b) == C.sizeof(vsf.VsfTrackStats)
+    assert int(c) == C.sizeof(vsf.VsfInfo) and int(d) == vsf.COMM_ID_BYTES
+    assert p.lk_cache_max_bytes == 0
+
+
+def test_comm_for_a_world_of_one_needs_no_gpu_and_no_rccl(vsf):
+    """vsf_comm_create with nranks == 1 is host-only bookkeeping; bad ranks are refused."""
+    lib = vsf.lib()
+    h = C.c_void_p()
+    assert lib.vsf_comm_create(None, 0, 1, 0, C.byref(h)) == vsf.VSF_OK and h.value
+    r, n = C.c_int32(-1), C.c_int32(-1)
+    assert lib.vsf_comm_rank(h, C.byref(r), C.byref(n)) == vsf.VSF_OK and (r.value, n.value) == (0, 1)
+    lib.vsf_comm_destroy(h)
+    for rank, nranks in ((1, 1), (-1, 2), (0, 0)):
+        assert lib.vsf_comm_create(None, rank, nranks, 0, C.byref(h)) == vsf.VSF_E_INVALID
+    assert lib.vsf_comm_create(None, 0, 2, 0, C.byref(h)) == vsf.VSF_E_INVALID   # several ranks need the unique id
 
 
 def test_product_never_touches_the_oracle():

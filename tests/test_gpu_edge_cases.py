@@ -102,10 +102,21 @@ def test_error_returns(vsf, synth):
         vsf.Context(vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, min_distance=40.0))  # disc radius > 31
     ctx = vsf.Context(vsf.default_params(width=200, height=150))
     ids, xy, age = _table(ctx.capacity)
-    wrong = np.zeros((100, 100), np.uint8)
+    # a tracker that holds a previous frame refuses another size (cv::calcOpticalFlowPyrLK would throw) ...
+    ctx.track(np.zeros((150, 200), np.uint8), ids, xy, age, 0)
     with pytest.raises(vsf.VsfError) as e:
-        ctx.detect(wrong, ids, xy, age, 0)
+        ctx.track(np.zeros((100, 100), np.uint8), ids, xy, age, 0)
     assert e.value.code == -4  # VSF_E_GEOMETRY
+    # ... a frame no larger than the LK window cannot be served at all ...
+    with pytest.raises(vsf.VsfError) as e:
+        ctx.detect(np.zeros((16, 16), np.uint8), ids, xy, age, 0)
+    assert e.value.code == -4
+    # ... and a context of several streams keeps its size
+    bctx = vsf.Context(vsf.default_params(width=200, height=150, streams=2))
+    with pytest.raises(vsf.VsfError) as e:
+        bctx.detect(np.zeros((100, 100), np.uint8), ids, xy, age, 0)
+    assert e.value.code == -4
+    bctx.close()
     with pytest.raises(vsf.VsfError) as e:
         ctx.track(np.zeros((150, 200), np.uint8), ids, xy, age, ctx.capacity + 1)
     assert e.value.code == -3  # VSF_E_CAPACITY

@@ -35,8 +35,8 @@ def test_example_binary_is_built():
 
 
 @pytest.mark.gpu
-def test_cpp_example_from_disk_matches_oracle(oracle, synth, tmp_path):
-    w, h, n = 376, 240, 13
+@pytest.mark.parametrize("w,h,n", [(376, 240, 13), (752, 480, 12)])  # the second: C1 at its own size (EuRoC cam0)
+def test_cpp_example_from_disk_matches_oracle(oracle, synth, tmp_path, w, h, n):
     frames, _ = synth.sequence(91, w, h, n)
     root = str(tmp_path / "V1_01_easy")
     calib = make_dataset(root, frames)

@@ -244,3 +244,17 @@ def test_tracker_wrapper_semantics(oracle, synth):
     a.track(t1, f[1])
     oracle.Tracker(30, 0.01, 21, 3, 1.0).track_pair(t2, f[0], f[1])
     assert t1.as_dict() == t2.as_dict()
+
+
+def test_bgr2gray_known_answers(oracle):
+    """cv::cvtColor(CV_BGR2GRAY), 8-bit: the grey levels OpenCV documents for the primaries (B 29, G 150, R 76),
+    grey stays grey (the three weights sum to 2^14), and an independent numpy statement of the fixed-point rule."""
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [17, 17, 17], [1, 2, 3]]], np.uint8)
+    g = oracle.bgr2gray(px)[0]
+    assert list(g[:6]) == [29, 150, 76, 255, 0, 17]
+    rng = np.random.default_rng(3)
+    for cn in (3, 4):
+        img = rng.integers(0, 256, (37, 53, cn), dtype=np.uint8)
+        ref = ((img[..., 0].astype(np.int64) * 1868 + img[..., 1].astype(np.int64) * 9617 +
+                img[..., 2].astype(np.int64) * 4899 + 8192) >> 14).astype(np.uint8)
+        assert np.array_equal(oracle.bgr2gray(img), ref)

@@ -19,9 +19,12 @@ def sq(counter):
         if "lk_fb_kernel" in row["kernel"] and row["counter"] == counter:
             return float(row["mean_per_launch"])
     return None
+sys.path.insert(0, root)
+from bench import csrc_sha16  # noqa: E402 -- the hash bench.py checks before it trusts this file
 P = 752 * 480 + 376 * 240 + 188 * 120 + 94 * 60
 out = {
     "kernel": name.replace("void vsf::", ""), "streams": streams, "config_name": "C2",
+    "csrc_sha16": csrc_sha16(),
     "config": "C2 752x480, 4 levels, 21x21, ~245 features/stream, 6 % of every frame under moving occluders",
     "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
     "hbm_bytes_per_launch": int((f + w) * 1024),

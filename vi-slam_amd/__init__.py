@@ -29,7 +29,10 @@ ABI_SYMBOLS = [
     "vsf_reset_tracker", "vsf_debug_pyramid", "vsf_debug_lk", "vsf_debug_min_eig", "vsf_debug_anms",
     "vsf_debug_set_cand_cap",
     "vsf_batch_frontend_post_track", "vsf_unproject", "vsf_debug_lssd", "vsf_debug_lssd_pyramid", "vsf_debug_lssd_inverse3",
-    "vsf_profile_enable", "vsf_profile_read", "vsf_lk_points_noalloc",
+    "vsf_profile_enable", "vsf_profile_read", "vsf_lk_points_noalloc", "vsf_get_info",
+    "vsf_detect_bgr", "vsf_batch_bgr_to_gray",
+    "vsf_comm_unique_id", "vsf_comm_create", "vsf_comm_wrap", "vsf_comm_destroy", "vsf_comm_rank",
+    "vsf_comm_last_error", "vsf_gather_tracks", "vsf_debug_sclk_probe",
 ]
 
 
@@ -45,8 +48,13 @@ class VsfParams(C.Structure):
         ("anms_quality_level", C.c_double), ("anms_block_size", C.c_int32),
         ("anms_ignore_edge", C.c_int32), ("anms_tolerance", C.c_double),
         ("tracker_kind", C.c_int32), ("lssd_levels", C.c_int32), ("lssd_max_iterations", C.c_int32),
-        ("lssd_max_recovered_dist", C.c_double),
+        ("lssd_max_recovered_dist", C.c_double), ("lk_cache_max_bytes", C.c_int64),
     ]
+
+
+class VsfInfo(C.Structure):
+    _fields_ = [("lk_cache_bytes", C.c_int64), ("width", C.c_int32), ("height", C.c_int32), ("streams", C.c_int32),
+                ("capacity", C.c_int32), ("levels", C.c_int32), ("reserved", C.c_int32)]
 
 
 DETECTOR_BUCKETING = 0
@@ -107,6 +115,9 @@ def lib():
         L.vsf_last_error.argtypes = [C.c_void_p]
         L.vsf_destroy.argtypes = [C.c_void_p]
         L.vsf_destroy.restype = None
+        L.vsf_comm_destroy.argtypes = [C.c_void_p]
+        L.vsf_comm_destroy.restype = None
+        L.vsf_comm_last_error.restype = C.c_char_p
         _lib = L
     return _lib
 
@@ -140,6 +151,11 @@ class Context:
         cap = C.c_int32()  # the library's own answer (the default depends on the detector kind)
         self._chk(lib().vsf_batch_device_tables(self._h, None, None, None, None, C.byref(cap)))
         self.capacity = cap.value
+
+    def info(self):
+        i = VsfInfo()
+        self._chk(lib().vsf_get_info(self._h, C.byref(i)))
+        return i
 
     def close(self):
         if getattr(self, "_h", None):
@@ -186,15 +202,25 @@ class Context:
         return nn.value, (st.input, st.forward, st.backward, st.verified)
 
     def detect(self, img, ids, xy, age, n, mask=None):
-        img, stride = self._frame(img)
-        h, w = img.shape
+        """UpdateDetection; an [h][w][3 or 4] array is a BGR(A) frame (cv::cvtColor on the device, vsf_detect_bgr)."""
         nn = C.c_int32(n)
         mptr, mstride = None, 0
         if mask is not None:
             mask, mstride = self._frame(mask)
             mptr = _vp(mask)
-        self._chk(lib().vsf_detect(self._h, _vp(img), w, h, stride, mptr, mstride, _vp(ids), _vp(xy),
-                                   _vp(age), C.byref(nn), len(ids)))
+        if np.ndim(img) == 3 and np.shape(img)[2] != 1:
+            img = np.ascontiguousarray(img, np.uint8)
+            h, w, cn = img.shape
+            self._chk(lib().vsf_detect_bgr(self._h, _vp(img), w, h, w * cn, cn, mptr, mstride, _vp(ids), _vp(xy),
+                                           _vp(age), C.byref(nn), len(ids)))
+        else:
+            if np.ndim(img) == 3:
+                img = np.asarray(img)[:, :, 0]
+            img, stride = self._frame(img)
+            h, w = img.shape
+            self._chk(lib().vsf_detect(self._h, _vp(img), w, h, stride, mptr, mstride, _vp(ids), _vp(xy),
+                                       _vp(age), C.byref(nn), len(ids)))
+        self.width, self.height = w, h  # a single-stream context follows the caller's frame size
         return nn.value
 
     def step(self, img, ids, xy, age, n, mask=None):
@@ -233,6 +259,12 @@ class Context:
                                          row_stride, C.c_void_p(d_masks), C.c_int64(mask_stride),
                                          mask_row_stride, C.c_void_p(stream)))
 
+    def batch_bgr_to_gray(self, d_bgr, bgr_frame_stride, bgr_row_stride, channels, d_gray, gray_frame_stride,
+                          gray_row_stride, stream=0):
+        self._chk(lib().vsf_batch_bgr_to_gray(self._h, C.c_void_p(d_bgr), C.c_int64(bgr_frame_stride), bgr_row_stride,
+                                              channels, C.c_void_p(d_gray), C.c_int64(gray_frame_stride),
+                                              gray_row_stride, C.c_void_p(stream)))
+
     def batch_step(self, d_frames, frame_stride, row_stride, stream=0):
         self._chk(lib().vsf_batch_step(self._h, C.c_void_p(d_frames), C.c_int64(frame_stride),
                                        row_stride, C.c_void_p(stream)))
@@ -266,6 +298,12 @@ class Context:
 
     def batch_export_tracks(self, d_records, stream=0):
         self._chk(lib().vsf_batch_export_tracks(self._h, C.c_void_p(d_records), C.c_void_p(stream)))
+
+    def gather_tracks(self, comm, d_recv, stream=0):
+        """vsf_gather_tracks: this rank's records into its slot of d_recv (device address of world x streams x capacity
+        x 24 bytes), then one RCCL all-gather in place.  comm: a Comm, or None for a world of one."""
+        self._chk(lib().vsf_gather_tracks(self._h, comm._h if comm is not None else None, C.c_void_p(d_recv),
+                                          C.c_void_p(stream)))
 
     def batch_status(self):
         st = np.zeros(self.streams, np.int32)
@@ -358,7 +396,8 @@ class Context:
 
     def debug_anms(self, stream=0):
         """(mask GFTT saw [h][w], detected keypoints [n][2] in cv order) of the last ANMS detection."""
-        w, h = self.params.width, self.params.height
+        i = self.info()
+        w, h = i.width, i.height
         flag = np.zeros((h, w), np.uint8)
         kp = np.zeros((8192, 2), np.int16)
         n = C.c_int32(0)
@@ -366,6 +405,12 @@ class Context:
         return flag, kp[:n.value].copy()
 
     # ---- profiling ----
+    def sclk_probe(self, spin_us=20000):
+        """(shader clock MHz, constant counter MHz) measured over spin_us on a stream of its own (vsf_debug_sclk_probe)."""
+        a, b = C.c_double(), C.c_double()
+        self._chk(lib().vsf_debug_sclk_probe(self._h, int(spin_us), C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def profile_enable(self, on=True):
         self._chk(lib().vsf_profile_enable(self._h, 1 if on else 0))
 
@@ -374,6 +419,42 @@ class Context:
         cnt = (C.c_int32 * len(KERNEL_NAMES))()
         self._chk(lib().vsf_profile_read(self._h, ms, cnt))
         return {k: (float(ms[i]), int(cnt[i])) for i, k in enumerate(KERNEL_NAMES)}
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """ncclGetUniqueId through the library (rank 0); hand the bytes to the other ranks by any means."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    rc = lib().vsf_comm_unique_id(buf)
+    if rc != VSF_OK:
+        raise VsfError(rc, lib().vsf_comm_last_error().decode())
+    return bytes(buf)
+
+
+class Comm:
+    """Owner of one vsf_comm (an RCCL communicator; none at all for a world of one)."""
+
+    def __init__(self, unique_id, rank, nranks, device_id=0):
+        self._h = C.c_void_p()
+        idbuf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id) if unique_id is not None else None
+        rc = lib().vsf_comm_create(idbuf, rank, nranks, device_id, C.byref(self._h))
+        if rc != VSF_OK:
+            self._h = None
+            raise VsfError(rc, lib().vsf_comm_last_error().decode())
+        self.rank, self.nranks = rank, nranks
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().vsf_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def lk_points_noalloc(params, d_prev, prev_stride, d_next, next_stride, d_prev_pts, d_next_pts, d_status, n, stream=0):

@@ -9,7 +9,11 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened at run time (vsf_comm_*)
+
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "vsf_kernels.hpp"
@@ -51,6 +55,9 @@ struct vsf_ctx {
   uint8_t* own_frame[2] = {};  // host-API staging of stream 0 (ping-pong: previous frame stays resident)
   uint8_t* h_stage = nullptr;  // pinned host block of the host-pointer API: frame | mask | table pack (first use)
   uint8_t* d_pack = nullptr;   // device side of the table pack
+  uint8_t* h_bgr = nullptr;    // multi-channel detector input (vsf_detect_bgr): pinned host + device copy, first use
+  uint8_t* d_bgr = nullptr;
+  size_t bgr_bytes = 0;
   // stateless pair / debug buffers (single stream), allocated lazily
   PyrSet pair_pyr[2];
   uint8_t* pair_frame[2] = {};
@@ -68,6 +75,7 @@ struct vsf_ctx {
   int* d_stats = nullptr;
   int* d_tslot = nullptr;      // [B][cap] LK template cache slot of each table entry
   LkCacheBuf lkc[2] = {};      // LK template cache, ping-pong with the pyramids (tpl == nullptr: disabled)
+  size_t lkc_bytes = 0;        // device bytes the cache holds (0: none)
   int epoch = 0;               // bumped by every Track call
   int* d_status = nullptr;
   uint64_t* d_maxidx = nullptr;
@@ -139,9 +147,64 @@ int fail(vsf_ctx* c, int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(c, VSF_E_HIP, "%s: %s", #call, hipGetErrorString(e_));    \
   } while (0)
 
+// Every extern "C" entry runs on the context's device and leaves the calling thread's current device as it found it.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() {
+    if (switched && prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+#define VSF_ON_DEVICE(c)                 \
+  DeviceGuard dev_guard_((c)->p.device_id); \
+  HIPCHK(c, dev_guard_.err)
+
+// The host-pointer entries move everything through ONE pinned block (h_stage) with asynchronous copies on the null
+// stream.  Whatever way such an entry returns, no copy may still be reading or writing that block: an immediate
+// retry would memcpy into it under a running H2D copy.  The success path synchronises explicitly and disarms.
+struct StageSync {
+  bool armed = true;
+  ~StageSync() {
+    if (armed) (void)hipStreamSynchronize(nullptr);
+  }
+};
+
+void free_lk_cache(vsf_ctx* c) {
+  for (int i = 0; i < 2; i++) {
+    if (c->lkc[i].tpl) (void)hipFree(c->lkc[i].tpl);
+    if (c->lkc[i].hdr) (void)hipFree(c->lkc[i].hdr);
+    if (c->lkc[i].tag) (void)hipFree(c->lkc[i].tag);
+    c->lkc[i] = LkCacheBuf{};
+  }
+  c->lkc_bytes = 0;
+}
+
+// The LK template cache is the one optional allocation of a context (results are identical without it): when a
+// mandatory or lazily allocated buffer does not fit, the cache is given back and the allocation tried again.
 template <typename T>
 int dalloc(vsf_ctx* c, T** p, size_t count) {
-  HIPCHK(c, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T) ? count * sizeof(T) : 16));
+  const size_t bytes = count * sizeof(T) ? count * sizeof(T) : 16;
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
+  if (e == hipErrorOutOfMemory && c->lkc[0].tpl) {
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();  // kernels in flight may still use the cache
+    free_lk_cache(c);
+    e = hipMalloc(reinterpret_cast<void**>(p), bytes);
+  }
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(c, e == hipErrorOutOfMemory ? VSF_E_NOMEM : VSF_E_HIP, "hipMalloc(%zu bytes): %s", bytes, hipGetErrorString(e));
+  }
   return VSF_OK;
 }
 
@@ -676,10 +739,63 @@ int read_table0(vsf_ctx* c, uint64_t* ids, double* xy, uint32_t* age, int* n, in
   return VSF_OK;
 }
 
-int check_geom(vsf_ctx* c, int w, int h, int stride) {
-  if (w != c->p.width || h != c->p.height)
-    return fail(c, VSF_E_GEOMETRY, "frame %dx%d does not match the context's %dx%d", w, h, c->p.width, c->p.height);
+// The reference takes any cv::Mat per call (FeatureDetectorBase.hpp:17-20): a SINGLE-STREAM context whose frame size
+// differs from the one it was created for re-creates its buffers for the new size (a fresh context with the same
+// parameters, swapped in).  What survives: the detector's max_feature_index_ and the profiling switch.  What does
+// not: the tracker's previous frame (cv::calcOpticalFlowPyrLK throws when prev and next differ in size, so a
+// tracker that has one refuses the new size instead: `keeps_prev`), test overrides.  Batched contexts keep
+// their size (their device-resident batches are sized by it).
+int regeom(vsf_ctx* c, int w, int h) {
+  if (c->B != 1)
+    return fail(c, VSF_E_GEOMETRY, "frame %dx%d does not match the batched context's %dx%d", w, h, c->p.width, c->p.height);
+  vsf_params np = c->p;
+  np.width = w;
+  np.height = h;
+  np.capacity = c->cap;
+  vsf_ctx* nc = nullptr;
+  int rc = vsf_create(&np, &nc);
+  if (rc)
+    return fail(c, rc == VSF_E_INVALID ? VSF_E_GEOMETRY : rc, "frame %dx%d: the context cannot be re-created for this size (code %d)",
+                w, h, rc);
+  if (hipDeviceSynchronize() != hipSuccess ||
+      hipMemcpy(nc->d_maxidx, c->d_maxidx, sizeof(uint64_t), hipMemcpyDeviceToDevice) != hipSuccess) {
+    vsf_destroy(nc);
+    return fail(c, VSF_E_HIP, "regeom: copy of the detector state failed");
+  }
+  nc->prof = c->prof;
+  nc->ev_used.swap(c->ev_used);  // recorded timings stay readable
+  nc->ev_free.swap(c->ev_free);
+  std::swap(*c, *nc);
+  vsf_destroy(nc);  // the old buffers
+  return VSF_OK;
+}
+
+// keeps_prev: the call continues from a stored previous frame, which pins the size
+int check_geom(vsf_ctx* c, int w, int h, int stride, bool keeps_prev = false) {
+  if (w <= 0 || h <= 0) return fail(c, VSF_E_INVALID, "frame %dx%d", w, h);
   if (stride < w) return fail(c, VSF_E_INVALID, "stride %d < width %d", stride, w);
+  if (w == c->p.width && h == c->p.height) return VSF_OK;
+  if (keeps_prev)
+    return fail(c, VSF_E_GEOMETRY, "frame %dx%d after a previous frame of %dx%d (cv::calcOpticalFlowPyrLK would throw); "
+                "vsf_reset_tracker first", w, h, c->p.width, c->p.height);
+  DeviceGuard dg(c->p.device_id);
+  if (dg.err != hipSuccess) return fail(c, VSF_E_HIP, "hipSetDevice");
+  return regeom(c, w, h);
+}
+
+// Checked BEFORE anything runs: once the tracker and the detector have run, the previous frame, the id counter and
+// the device table have advanced, and a caller whose arrays turn out too short could not retry the frame.
+int check_caller_capacity(vsf_ctx* c, int n, int capacity) {
+  if (n < 0 || n > c->cap) return fail(c, VSF_E_CAPACITY, "table of %d entries exceeds capacity %d", n, c->cap);
+  if (n > capacity) return fail(c, VSF_E_CAPACITY, "table of %d entries exceeds the caller's capacity %d", n, capacity);
+  // what the call can leave in the table: the entries it came with plus what the detector can add
+  long long most = (long long)n + (c->p.detector_kind == VSF_DETECTOR_ANMS
+                                       ? (long long)c->anms.nfeatures
+                                       : (long long)c->ncell * (c->grid_max > 0 ? c->grid_max : 0));
+  if (most > c->cap) most = c->cap;
+  if (capacity < most)
+    return fail(c, VSF_E_CAPACITY, "caller capacity %d below the %lld entries this call may produce; nothing was run",
+                capacity, most);
   return VSF_OK;
 }
 
@@ -739,13 +855,14 @@ void vsf_default_params(vsf_params* p) {
   p->lssd_levels = 3;
   p->lssd_max_iterations = 5;
   p->lssd_max_recovered_dist = 0.09;
+  p->lk_cache_max_bytes = 0;  // default limit (16 GiB)
 }
 
 const char* vsf_last_error(const vsf_ctx* ctx) { return ctx ? ctx->err : "null context"; }
 
 void vsf_destroy(vsf_ctx* c) {
   if (!c) return;
-  (void)hipSetDevice(c->p.device_id);
+  DeviceGuard dev_guard_(c->p.device_id);
   (void)hipDeviceSynchronize();
   for (int i = 0; i < 2; i++) {
     for (int l = 0; l < MAXL; l++) {
@@ -761,12 +878,10 @@ void vsf_destroy(vsf_ctx* c) {
   }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   if (c->d_pack) (void)hipFree(c->d_pack);
+  if (c->h_bgr) (void)hipHostFree(c->h_bgr);
+  if (c->d_bgr) (void)hipFree(c->d_bgr);
   if (c->d_tslot) (void)hipFree(c->d_tslot);
-  for (int i = 0; i < 2; i++) {
-    if (c->lkc[i].tpl) (void)hipFree(c->lkc[i].tpl);
-    if (c->lkc[i].hdr) (void)hipFree(c->lkc[i].hdr);
-    if (c->lkc[i].tag) (void)hipFree(c->lkc[i].tag);
-  }
+  free_lk_cache(c);
   void* lssd_bufs[] = {c->d_lssd_ids, c->d_lssd_xy, c->d_lssd_n};
   for (void* b : lssd_bufs)
     if (b) (void)hipFree(b);
@@ -823,7 +938,8 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || p->device_id < 0 || p->device_id >= ndev)
     return VSF_E_HIP;  // no GPU: fail loudly, there is no CPU path
-  if (hipSetDevice(p->device_id) != hipSuccess) return VSF_E_HIP;
+  DeviceGuard dev_guard_(p->device_id);
+  if (dev_guard_.err != hipSuccess) return VSF_E_HIP;
 
   vsf_ctx* c = new (std::nothrow) vsf_ctx();
   if (!c) return VSF_E_NOMEM;
@@ -996,12 +1112,15 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   }
 #undef A
   // LK template cache (vsf_lk.hpp): 2 x streams x capacity x levels x 2.5 KB.  Optional: a context that cannot
-  // have it (other tracker, windows above 21, more than 16 GiB, allocation failure) just recomputes templates.
-  if (!rc && !use_lssd && lk_seg_template(c->lk.seglen) <= 8) {
+  // have it (other tracker, windows above 21, above the byte limit of vsf_params.lk_cache_max_bytes -- 16 GiB by
+  // default, negative = never --, allocation failure) just recomputes templates.  It is allocated LAST and is the
+  // first thing given back when a later allocation of this context does not fit (dalloc).
+  if (!rc && !use_lssd && lk_seg_template(c->lk.seglen) <= 8 && p->lk_cache_max_bytes >= 0) {
     const size_t slots = (size_t)B * c->cap;
     const size_t tpl_b = slots * c->nlevels * LK_TPL_U4 * sizeof(uint4), hdr_b = slots * c->nlevels * sizeof(float4),
                  tag_b = slots * sizeof(float4);
-    if (2 * (tpl_b + hdr_b + tag_b) <= ((size_t)16 << 30)) {
+    const size_t limit = p->lk_cache_max_bytes > 0 ? (size_t)p->lk_cache_max_bytes : ((size_t)16 << 30);
+    if (2 * (tpl_b + hdr_b + tag_b) <= limit) {
       bool ok = true;
       for (int i = 0; i < 2 && ok; i++) {
         ok = hipMalloc((void**)&c->lkc[i].tpl, tpl_b) == hipSuccess && hipMalloc((void**)&c->lkc[i].hdr, hdr_b) == hipSuccess &&
@@ -1009,12 +1128,9 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
       }
       if (!ok) {
         (void)hipGetLastError();
-        for (int i = 0; i < 2; i++) {
-          if (c->lkc[i].tpl) (void)hipFree(c->lkc[i].tpl);
-          if (c->lkc[i].hdr) (void)hipFree(c->lkc[i].hdr);
-          if (c->lkc[i].tag) (void)hipFree(c->lkc[i].tag);
-          c->lkc[i] = LkCacheBuf{};
-        }
+        free_lk_cache(c);
+      } else {
+        c->lkc_bytes = 2 * (tpl_b + hdr_b + tag_b);
       }
     }
   }
@@ -1066,6 +1182,18 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   return VSF_OK;
 }
 
+int vsf_get_info(const vsf_ctx* c, vsf_info* out) {
+  if (!c || !out) return VSF_E_INVALID;
+  memset(out, 0, sizeof(*out));
+  out->lk_cache_bytes = (int64_t)c->lkc_bytes;
+  out->width = c->p.width;
+  out->height = c->p.height;
+  out->streams = c->B;
+  out->capacity = c->cap;
+  out->levels = c->nlevels;
+  return VSF_OK;
+}
+
 int vsf_reset_tracker(vsf_ctx* c) {
   if (!c) return VSF_E_INVALID;
   c->has_prev = false;
@@ -1074,14 +1202,14 @@ int vsf_reset_tracker(vsf_ctx* c) {
 
 int vsf_get_max_feature_index(vsf_ctx* c, int32_t stream, uint64_t* out) {
   if (!c || !out || stream < 0 || stream >= c->B) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   HIPCHK(c, hipMemcpy(out, c->d_maxidx + stream, 8, hipMemcpyDeviceToHost));
   return VSF_OK;
 }
 
 int vsf_set_max_feature_index(vsf_ctx* c, int32_t stream, uint64_t value) {
   if (!c || stream < 0 || stream >= c->B) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   HIPCHK(c, hipMemcpy(c->d_maxidx + stream, &value, 8, hipMemcpyHostToDevice));
   return VSF_OK;
 }
@@ -1092,13 +1220,14 @@ int vsf_set_max_feature_index(vsf_ctx* c, int32_t stream, uint64_t value) {
 int vsf_track(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, uint64_t* ids, double* xy,
               uint32_t* age, int32_t* n_inout, vsf_track_stats* stats) {
   if (!c || !img || !n_inout) return VSF_E_INVALID;
-  int rc = check_geom(c, w, h, stride);
+  int rc = check_geom(c, w, h, stride, c->has_prev);
   if (rc) return rc;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   const int n = *n_inout;
   if (n > 0 && (!ids || !xy || !age)) return VSF_E_INVALID;
   if (n < 0 || n > c->cap) return fail(c, VSF_E_CAPACITY, "table of %d entries exceeds capacity %d", n, c->cap);
   uint8_t* slot = c->own_frame[c->cur ^ 1];
+  StageSync stage_sync;  // from here on copies may be in flight on the pinned block
   rc = upload_frame(c, slot, img, w, h, stride);
   if (rc) return rc;
   const bool first = !c->has_prev;
@@ -1107,6 +1236,7 @@ int vsf_track(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stri
   if (!rc && !first) rc = download_table0_async(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(nullptr));
+  stage_sync.armed = false;
   if (first) {  // :29-32 table untouched
     if (stats) stats->input = stats->forward = stats->backward = stats->verified = n;
     return VSF_OK;
@@ -1123,9 +1253,10 @@ int vsf_track_pair(vsf_ctx* c, const uint8_t* prev, int32_t prev_stride, const u
   int rc = check_geom(c, w, h, prev_stride);
   if (!rc) rc = check_geom(c, w, h, cur_stride);
   if (rc) return rc;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   const int n = *n_inout;
   if (n > 0 && (!ids || !xy || !age)) return VSF_E_INVALID;
+  StageSync stage_sync;
   rc = ensure_pair(c);
   if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, prev_stride);
   if (!rc) rc = upload_frame(c, c->pair_frame[1], cur, w, h, cur_stride, 1);
@@ -1141,27 +1272,92 @@ int vsf_track_pair(vsf_ctx* c, const uint8_t* prev, int32_t prev_stride, const u
   if (!rc) rc = download_table0_async(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(nullptr));
+  stage_sync.armed = false;
   return read_table0(c, ids, xy, age, n_inout, n, stats, nullptr);
 }
 
-int vsf_detect(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, const uint8_t* mask,
-               int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout, int32_t capacity) {
+}  // extern "C"
+
+namespace {
+// vsf_detect / vsf_detect_bgr: cn = 1 (grey) or 3 / 4 interleaved channels, B first (converted on the device)
+int detect_host(vsf_ctx* c, const uint8_t* img, int w, int h, int stride, int cn, const uint8_t* mask, int mask_stride,
+                uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout, int capacity) {
   if (!c || !img || !n_inout || !ids || !xy || !age) return VSF_E_INVALID;
-  int rc = check_geom(c, w, h, stride);
+  if (cn != 1 && cn != 3 && cn != 4) return fail(c, VSF_E_INVALID, "%d channels (1, 3 or 4)", cn);
+  if (stride < w * cn) return fail(c, VSF_E_INVALID, "stride %d < %d bytes per row", stride, w * cn);
+  int rc = check_geom(c, w, h, w);
   if (rc) return rc;
   if (mask && mask_stride < w) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
-  rc = upload_frame(c, c->det_frame, img, w, h, stride);
+  VSF_ON_DEVICE(c);
+  rc = check_caller_capacity(c, *n_inout, capacity);
+  if (rc) return rc;
+  StageSync stage_sync;
+  if (cn == 1) {
+    rc = upload_frame(c, c->det_frame, img, w, h, stride);
+  } else {
+    rc = ensure_stage(c);
+    const size_t row = (size_t)w * cn, bytes = row * h;
+    if (!rc && c->bgr_bytes < bytes) {  // first multi-channel frame (or a larger one): its own pinned + device pair
+      (void)hipStreamSynchronize(nullptr);
+      if (c->h_bgr) (void)hipHostFree(c->h_bgr);
+      if (c->d_bgr) (void)hipFree(c->d_bgr);
+      c->h_bgr = nullptr, c->d_bgr = nullptr, c->bgr_bytes = 0;
+      if (hipHostMalloc((void**)&c->h_bgr, bytes, hipHostMallocDefault) != hipSuccess) rc = fail(c, VSF_E_NOMEM, "pinned BGR staging");
+      if (!rc) rc = dalloc(c, &c->d_bgr, bytes);
+      if (!rc) c->bgr_bytes = bytes;
+    }
+    if (!rc) {
+      if ((size_t)stride == row)
+        memcpy(c->h_bgr, img, bytes);
+      else
+        for (int y = 0; y < h; y++) memcpy(c->h_bgr + (size_t)y * row, img + (size_t)y * stride, row);
+      if (hipMemcpyAsync(c->d_bgr, c->h_bgr, bytes, hipMemcpyHostToDevice, nullptr) != hipSuccess) rc = fail(c, VSF_E_HIP, "BGR upload");
+    }
+    if (!rc) {
+      hipLaunchKernelGGL(bgr2gray_kernel, dim3((w + 255) / 256, (h + 3) / 4, 1), dim3(256), 0, nullptr, c->d_bgr,
+                         (long long)bytes, (int)row, cn, w, h, c->det_frame, (long long)w * h, w);
+      if (hipGetLastError() != hipSuccess) rc = fail(c, VSF_E_HIP, "bgr2gray launch");
+    }
+  }
   if (!rc && mask) rc = upload_frame(c, c->det_mask, mask, w, h, mask_stride, 1);
   if (!rc) rc = upload_table0(c, ids, xy, age, *n_inout);  // also clears the status word
   if (!rc) rc = detect_impl(c, own_ref(c, c->det_frame), mask ? c->det_mask : nullptr, (long long)w * h, w, 1, nullptr);
   if (!rc) rc = download_table0_async(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(nullptr));
+  stage_sync.armed = false;
   int st = 0;
   rc = read_table0(c, ids, xy, age, n_inout, capacity, nullptr, &st);
   if (rc) return rc;
   if (st) return fail(c, st, "feature table capacity %d exhausted during detection", c->cap);
+  return VSF_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int vsf_detect(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, const uint8_t* mask,
+               int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout, int32_t capacity) {
+  return detect_host(c, img, w, h, stride, 1, mask, mask_stride, ids, xy, age, n_inout, capacity);
+}
+
+int vsf_detect_bgr(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t stride, int32_t channels,
+                   const uint8_t* mask, int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout,
+                   int32_t capacity) {
+  if (channels == 1) return VSF_E_INVALID;  // vsf_detect
+  return detect_host(c, img, w, h, stride, channels, mask, mask_stride, ids, xy, age, n_inout, capacity);
+}
+
+int vsf_batch_bgr_to_gray(vsf_ctx* c, const uint8_t* d_bgr, int64_t bgr_frame_stride, int32_t bgr_row_stride,
+                          int32_t channels, uint8_t* d_gray, int64_t gray_frame_stride, int32_t gray_row_stride,
+                          void* hip_stream) {
+  if (!c || !d_bgr || !d_gray || (channels != 3 && channels != 4)) return VSF_E_INVALID;
+  if (bgr_row_stride < c->p.width * channels || gray_row_stride < c->p.width) return VSF_E_INVALID;
+  VSF_ON_DEVICE(c);
+  hipLaunchKernelGGL(bgr2gray_kernel, dim3((c->p.width + 255) / 256, (c->p.height + 3) / 4, c->B), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(hip_stream), d_bgr, (long long)bgr_frame_stride, bgr_row_stride, channels,
+                     c->p.width, c->p.height, d_gray, (long long)gray_frame_stride, gray_row_stride);
+  HIPCHK(c, hipGetLastError());
   return VSF_OK;
 }
 
@@ -1171,13 +1367,16 @@ int vsf_step(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t strid
              int32_t mask_stride, uint64_t* ids, double* xy, uint32_t* age, int32_t* n_inout, int32_t capacity,
              vsf_track_stats* stats) {
   if (!c || !img || !n_inout || !ids || !xy || !age) return VSF_E_INVALID;
-  int rc = check_geom(c, w, h, stride);
+  int rc = check_geom(c, w, h, stride, c->has_prev);
   if (rc) return rc;
   if (mask && mask_stride < w) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   const int n = *n_inout;
   uint8_t* slot = c->own_frame[c->cur ^ 1];
   const bool first = !c->has_prev;
+  rc = check_caller_capacity(c, n, capacity);
+  if (rc) return rc;
+  StageSync stage_sync;
   rc = upload_frame(c, slot, img, w, h, stride);
   if (!rc && mask) rc = upload_frame(c, c->det_mask, mask, w, h, mask_stride, 1);
   if (!rc) rc = upload_table0(c, ids, xy, age, n);
@@ -1186,6 +1385,7 @@ int vsf_step(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t strid
   if (!rc) rc = download_table0_async(c);
   if (rc) return rc;
   HIPCHK(c, hipStreamSynchronize(nullptr));
+  stage_sync.armed = false;
   int st = 0;
   rc = read_table0(c, ids, xy, age, n_inout, capacity, first ? nullptr : stats, &st);
   if (rc) return rc;
@@ -1200,7 +1400,7 @@ int vsf_step(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int32_t strid
 int vsf_batch_track(vsf_ctx* c, const uint8_t* d_frames, int64_t frame_stride_bytes, int32_t row_stride,
                     void* hip_stream) {
   if (!c || !d_frames || row_stride < c->p.width) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   FrameRef f;
   f.ptr = d_frames;
   f.sstride = frame_stride_bytes;
@@ -1212,7 +1412,7 @@ int vsf_batch_detect(vsf_ctx* c, const uint8_t* d_frames, int64_t frame_stride_b
                      const uint8_t* d_masks, int64_t mask_stride_bytes, int32_t mask_row_stride, void* hip_stream) {
   if (!c || !d_frames || row_stride < c->p.width) return VSF_E_INVALID;
   if (d_masks && mask_row_stride < c->p.width) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   FrameRef f;
   f.ptr = d_frames;
   f.sstride = frame_stride_bytes;
@@ -1231,7 +1431,7 @@ int vsf_batch_step(vsf_ctx* c, const uint8_t* d_frames, int64_t frame_stride_byt
 int vsf_batch_upload(vsf_ctx* c, int32_t first, int32_t count, const uint64_t* ids, const double* xy,
                      const uint32_t* age, const int32_t* n) {
   if (!c || first < 0 || count < 0 || first + count > c->B || !ids || !xy || !age || !n) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   for (int i = 0; i < count; i++)
     if (n[i] < 0 || n[i] > c->cap) return fail(c, VSF_E_CAPACITY, "stream %d: n=%d exceeds capacity", first + i, n[i]);
   const size_t o = (size_t)first * c->cap, T = (size_t)count * c->cap;
@@ -1246,7 +1446,7 @@ int vsf_batch_upload(vsf_ctx* c, int32_t first, int32_t count, const uint64_t* i
 int vsf_batch_download(vsf_ctx* c, int32_t first, int32_t count, uint64_t* ids, double* xy, uint32_t* age,
                        int32_t* n, vsf_track_stats* stats) {
   if (!c || first < 0 || count < 0 || first + count > c->B || !ids || !xy || !age || !n) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   HIPCHK(c, hipDeviceSynchronize());
   const size_t o = (size_t)first * c->cap, T = (size_t)count * c->cap;
   HIPCHK(c, hipMemcpy(ids, c->d_ids + o, T * 8, hipMemcpyDeviceToHost));
@@ -1269,7 +1469,7 @@ int vsf_batch_device_tables(vsf_ctx* c, void** ids, void** xy, void** age, void*
 
 int vsf_batch_export_tracks(vsf_ctx* c, void* d_records, void* hip_stream) {
   if (!c || !d_records) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   const long long total = (long long)c->B * c->cap;
   hipLaunchKernelGGL(export_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      reinterpret_cast<hipStream_t>(hip_stream), c->d_ids, c->d_xy, c->d_age, c->d_n, c->cap, total,
@@ -1280,7 +1480,7 @@ int vsf_batch_export_tracks(vsf_ctx* c, void* d_records, void* hip_stream) {
 
 int vsf_batch_status(vsf_ctx* c, int32_t* status) {
   if (!c || !status) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   HIPCHK(c, hipDeviceSynchronize());
   HIPCHK(c, hipMemcpy(status, c->d_status, (size_t)c->B * 4, hipMemcpyDeviceToHost));
   return VSF_OK;
@@ -1294,7 +1494,8 @@ int vsf_debug_pyramid(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
   if (!c || !img || !out_levels || !max_level_out) return VSF_E_INVALID;
   int rc = check_geom(c, w, h, stride);
   if (rc) return rc;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
+  StageSync stage_sync;
   rc = ensure_pair(c);
   if (!rc) rc = upload_frame(c, c->pair_frame[0], img, w, h, stride);
   if (!rc) rc = build_pyramid(c, own_ref(c, c->pair_frame[0]), c->pair_pyr[0], 1, nullptr);
@@ -1317,7 +1518,8 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
   if (!prev_pts || !next_pts || !status) return VSF_E_INVALID;
   int rc = check_geom(c, w, h, w);
   if (rc) return rc;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
+  StageSync stage_sync;  // its destructor covers every return below
   rc = ensure_pair(c);
   if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, w);
   if (!rc) rc = upload_frame(c, c->pair_frame[1], next, w, h, w, 1);
@@ -1367,7 +1569,8 @@ int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
   if (!c || !img || !out || cell < 0 || cell >= c->ncell) return VSF_E_INVALID;
   int rc = check_geom(c, w, h, stride);
   if (rc) return rc;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
+  StageSync stage_sync;
   rc = upload_frame(c, c->det_frame, img, w, h, stride);
   if (rc) return rc;
   const GridView G = grid_view(c);
@@ -1448,9 +1651,9 @@ int vsf_lk_points_noalloc(const vsf_params* p, const uint8_t* d_prev, int32_t pr
       off += ((size_t)lp[l] * lh[l] + 16 + 255) & ~(size_t)255;
     }
   if (off > VSF_NOALLOC_SCRATCH_BYTES) return VSF_E_CAPACITY;  // frame too large for the 4 MiB array (about 5.9 Mpixel)
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess) return VSF_E_HIP;
-  if (dev != p->device_id && hipSetDevice(p->device_id) != hipSuccess) return VSF_E_HIP;
+  DeviceGuard dev_guard_(p->device_id);  // the caller's current device is restored on return
+  if (dev_guard_.err != hipSuccess) return VSF_E_HIP;
+  (void)hipGetLastError();  // an error left by earlier work of the caller is not this call's
   uint8_t* base = nullptr;
   int rc = noalloc_scratch_ptr(p->device_id, &base);
   if (rc) return rc;
@@ -1495,7 +1698,7 @@ int vsf_batch_frontend_post_track(vsf_ctx* c, const vsf_camera_ds* cam, const vs
                                   const double* dt_since_keyframe, double* d_bearings, int32_t* is_keyframe_out,
                                   uint32_t* aged_out, void* hip_stream) {
   if (!c || !cam || !kp || !dt_since_keyframe || !d_bearings) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
   const int B = c->B;
   if (!c->d_fe_dt) {
@@ -1521,7 +1724,7 @@ int vsf_unproject(vsf_ctx* c, const vsf_camera_ds* cam, const double* xy, int32_
                   uint8_t* valid) {
   if (!c || !cam || n < 0 || (n > 0 && (!xy || !bearings))) return VSF_E_INVALID;
   if (n == 0) return VSF_OK;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   double *d_in = nullptr, *d_out = nullptr;
   uint8_t* d_ok = nullptr;
   int rc = dalloc(c, &d_in, (size_t)n * 2);
@@ -1560,7 +1763,8 @@ int vsf_debug_lssd(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t
   int rc = check_geom(c, w, h, w);
   if (rc) return rc;
   if (n == 0) return VSF_OK;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
+  StageSync stage_sync;
   rc = lssd_ensure_pair(c);
   if (!rc) rc = upload_frame(c, c->pair_frame[0], prev, w, h, w);
   if (!rc) rc = upload_frame(c, c->pair_frame[1], next, w, h, w, 1);
@@ -1591,7 +1795,7 @@ int vsf_debug_lssd(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t
 int vsf_debug_lssd_inverse3(vsf_ctx* c, const float* H, float* Hinv, int32_t n) {
   if (!c || n < 0 || (n > 0 && (!H || !Hinv))) return VSF_E_INVALID;
   if (n == 0) return VSF_OK;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   float *d_in = nullptr, *d_out = nullptr;
   int rc = dalloc(c, &d_in, (size_t)n * 9);
   if (!rc) rc = dalloc(c, &d_out, (size_t)n * 9);
@@ -1614,7 +1818,8 @@ int vsf_debug_lssd_pyramid(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h,
   if (level < 1 || level > c->lssd.levels) return VSF_E_INVALID;
   int rc = check_geom(c, w, h, stride);
   if (rc) return rc;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
+  StageSync stage_sync;
   rc = lssd_ensure_pair(c);
   if (!rc) rc = upload_frame(c, c->pair_frame[0], img, w, h, stride);
   if (!rc) rc = lssd_build_pyramid(c, own_ref(c, c->pair_frame[0]), c->lssd_pair_pyr[0], 1, nullptr);
@@ -1628,7 +1833,7 @@ int vsf_debug_lssd_pyramid(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h,
 int vsf_debug_anms(vsf_ctx* c, int32_t stream, uint8_t* flag_out, int16_t* kp_out, int32_t* n_kp_out) {
   if (!c || stream < 0 || stream >= c->B) return VSF_E_INVALID;
   if (c->p.detector_kind != VSF_DETECTOR_ANMS) return fail(c, VSF_E_INVALID, "not an ANMS context");
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   HIPCHK(c, hipDeviceSynchronize());
   const size_t fs = (size_t)c->p.width * c->p.height;
   if (flag_out) HIPCHK(c, hipMemcpy(flag_out, c->d_aflag + (size_t)stream * fs, fs, hipMemcpyDeviceToHost));
@@ -1653,6 +1858,34 @@ int vsf_debug_lk_stats(unsigned long long* out /* [512] */, int32_t reset) {
 }
 #endif
 
+int vsf_debug_sclk_probe(vsf_ctx* c, int32_t spin_us, double* sclk_mhz, double* realtime_mhz) {
+  if (!c || !sclk_mhz || spin_us < 1 || spin_us > 2000000) return VSF_E_INVALID;
+  VSF_ON_DEVICE(c);
+  int wall_khz = 0;
+  HIPCHK(c, hipDeviceGetAttribute(&wall_khz, hipDeviceAttributeWallClockRate, c->p.device_id));
+  if (wall_khz <= 0) return fail(c, VSF_E_HIP, "no wall clock rate");
+  unsigned long long* d = nullptr;
+  int rc = dalloc(c, &d, (size_t)4);
+  if (rc) return rc;
+  hipStream_t s = nullptr;
+  unsigned long long h[4] = {0, 0, 0, 0};
+  hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);  // runs beside whatever the other streams hold
+  if (e == hipSuccess) {
+    const unsigned long long ticks = (unsigned long long)spin_us * (unsigned long long)wall_khz / 1000ull;
+    hipLaunchKernelGGL(sclk_probe_kernel, dim3(1), dim3(64), 0, s, d, ticks);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+    (void)hipStreamDestroy(s);
+  }
+  (void)hipFree(d);
+  if (e != hipSuccess) return fail(c, VSF_E_HIP, "sclk probe: %s", hipGetErrorString(e));
+  if (h[1] == 0) return fail(c, VSF_E_HIP, "sclk probe: the constant-rate counter did not move");
+  *sclk_mhz = (double)h[0] / (double)h[1] * (double)wall_khz / 1000.0;
+  if (realtime_mhz) *realtime_mhz = (double)wall_khz / 1000.0;
+  return VSF_OK;
+}
+
 int vsf_profile_enable(vsf_ctx* c, int32_t on) {
   if (!c) return VSF_E_INVALID;
   c->prof = on != 0;
@@ -1661,7 +1894,7 @@ int vsf_profile_enable(vsf_ctx* c, int32_t on) {
 
 int vsf_profile_read(vsf_ctx* c, float* total_ms, int32_t* launches) {
   if (!c || !total_ms || !launches) return VSF_E_INVALID;
-  HIPCHK(c, hipSetDevice(c->p.device_id));
+  VSF_ON_DEVICE(c);
   HIPCHK(c, hipDeviceSynchronize());
   for (int k = 0; k < VSF_K_COUNT; k++) {
     total_ms[k] = 0.f;
@@ -1676,6 +1909,181 @@ int vsf_profile_read(vsf_ctx* c, float* total_ms, int32_t* launches) {
     c->ev_free.push_back(e);
   }
   c->ev_used.clear();
+  return VSF_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Native multi-GPU gather: one RCCL all-gather of the fixed-size track records over xGMI.
+// The path shards by independent streams, so this is the ONLY collective; a C++ host (the reference's
+// example loop, example/vslam/example_serialization.cpp:159-171, one process per GPU) needs nothing but
+// include/vsf.h for it.  librccl is opened at run time (dlopen by soname: a process that already
+// holds an RCCL -- PyTorch brings its own copy -- gets THAT one, so communicators and streams stay
+// compatible), never linked: single-GPU users do not need the library at all.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+  void* handle = nullptr;
+  decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+  decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+  decltype(&ncclCommDestroy) comm_destroy = nullptr;
+  decltype(&ncclAllGather) all_gather = nullptr;
+  decltype(&ncclCommCount) comm_count = nullptr;
+  decltype(&ncclCommUserRank) comm_user_rank = nullptr;
+  decltype(&ncclGetErrorString) get_error_string = nullptr;
+};
+std::mutex g_rccl_mu;
+RcclApi g_rccl;
+char g_comm_err[256] = "";
+
+const RcclApi* rccl_api() {
+  std::lock_guard<std::mutex> lock(g_rccl_mu);
+  if (g_rccl.handle) return &g_rccl;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (h) break;
+  }
+  if (!h) {
+    snprintf(g_comm_err, sizeof(g_comm_err), "librccl not found: %s", dlerror());
+    return nullptr;
+  }
+  RcclApi a;
+  a.handle = h;
+#define VSF_SYM(field, name)                                        \
+  a.field = reinterpret_cast<decltype(a.field)>(dlsym(h, name));    \
+  if (!a.field) {                                                   \
+    snprintf(g_comm_err, sizeof(g_comm_err), "librccl lacks %s", name); \
+    return nullptr;                                                 \
+  }
+  VSF_SYM(get_unique_id, "ncclGetUniqueId")
+  VSF_SYM(comm_init_rank, "ncclCommInitRank")
+  VSF_SYM(comm_destroy, "ncclCommDestroy")
+  VSF_SYM(all_gather, "ncclAllGather")
+  VSF_SYM(comm_count, "ncclCommCount")
+  VSF_SYM(comm_user_rank, "ncclCommUserRank")
+  VSF_SYM(get_error_string, "ncclGetErrorString")
+#undef VSF_SYM
+  g_rccl = a;
+  return &g_rccl;
+}
+}  // namespace
+
+struct vsf_comm {
+  ncclComm_t comm = nullptr;
+  int rank = 0, nranks = 1, device = 0;
+  bool owned = false;
+};
+
+extern "C" {
+
+const char* vsf_comm_last_error(void) { return g_comm_err; }
+
+int vsf_comm_unique_id(uint8_t* id /* [VSF_COMM_ID_BYTES] */) {
+  if (!id) return VSF_E_INVALID;
+  static_assert(sizeof(ncclUniqueId) == VSF_COMM_ID_BYTES, "ncclUniqueId size");
+  const RcclApi* a = rccl_api();
+  if (!a) return VSF_E_HIP;
+  ncclUniqueId u;
+  const ncclResult_t r = a->get_unique_id(&u);
+  if (r != ncclSuccess) {
+    snprintf(g_comm_err, sizeof(g_comm_err), "ncclGetUniqueId: %s", a->get_error_string(r));
+    return VSF_E_HIP;
+  }
+  memcpy(id, &u, sizeof(u));
+  return VSF_OK;
+}
+
+int vsf_comm_create(const uint8_t* id, int32_t rank, int32_t nranks, int32_t device_id, vsf_comm** out) {
+  if (!out) return VSF_E_INVALID;
+  *out = nullptr;
+  if (nranks < 1 || rank < 0 || rank >= nranks || (nranks > 1 && !id)) return VSF_E_INVALID;
+  vsf_comm* c = new (std::nothrow) vsf_comm();
+  if (!c) return VSF_E_NOMEM;
+  c->rank = rank;
+  c->nranks = nranks;
+  c->device = device_id;
+  if (nranks > 1) {  // a world of one needs no communicator (and no librccl)
+    const RcclApi* a = rccl_api();
+    if (!a) {
+      delete c;
+      return VSF_E_HIP;
+    }
+    DeviceGuard dg(device_id);
+    if (dg.err != hipSuccess) {
+      delete c;
+      return VSF_E_HIP;
+    }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof(u));
+    const ncclResult_t r = a->comm_init_rank(&c->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+      snprintf(g_comm_err, sizeof(g_comm_err), "ncclCommInitRank: %s", a->get_error_string(r));
+      delete c;
+      return VSF_E_HIP;
+    }
+    c->owned = true;
+  }
+  *out = c;
+  return VSF_OK;
+}
+
+int vsf_comm_wrap(void* nccl_comm, int32_t device_id, vsf_comm** out) {
+  if (!out || !nccl_comm) return VSF_E_INVALID;
+  *out = nullptr;
+  const RcclApi* a = rccl_api();
+  if (!a) return VSF_E_HIP;
+  vsf_comm* c = new (std::nothrow) vsf_comm();
+  if (!c) return VSF_E_NOMEM;
+  c->comm = static_cast<ncclComm_t>(nccl_comm);
+  c->device = device_id;
+  if (a->comm_count(c->comm, &c->nranks) != ncclSuccess || a->comm_user_rank(c->comm, &c->rank) != ncclSuccess) {
+    snprintf(g_comm_err, sizeof(g_comm_err), "ncclCommCount / ncclCommUserRank failed on the given communicator");
+    delete c;
+    return VSF_E_HIP;
+  }
+  *out = c;
+  return VSF_OK;
+}
+
+void vsf_comm_destroy(vsf_comm* c) {
+  if (!c) return;
+  if (c->owned && c->comm) {
+    const RcclApi* a = rccl_api();
+    DeviceGuard dg(c->device);
+    if (a) (void)a->comm_destroy(c->comm);
+  }
+  delete c;
+}
+
+int vsf_comm_rank(const vsf_comm* c, int32_t* rank, int32_t* nranks) {
+  if (!c) return VSF_E_INVALID;
+  if (rank) *rank = c->rank;
+  if (nranks) *nranks = c->nranks;
+  return VSF_OK;
+}
+
+int vsf_gather_tracks(vsf_ctx* c, vsf_comm* comm, void* d_recv, void* hip_stream) {
+  if (!c || !d_recv) return VSF_E_INVALID;
+  const int nranks = comm ? comm->nranks : 1, rank = comm ? comm->rank : 0;
+  if (comm && comm->device != c->p.device_id) return fail(c, VSF_E_INVALID, "communicator of device %d, context of device %d", comm->device, c->p.device_id);
+  VSF_ON_DEVICE(c);
+  hipStream_t s = reinterpret_cast<hipStream_t>(hip_stream);
+  const size_t bytes = (size_t)c->B * c->cap * sizeof(TrackRecord);
+  // this rank's records straight into its slot of the receive buffer: the all-gather then runs in place
+  uint8_t* mine = static_cast<uint8_t*>(d_recv) + (size_t)rank * bytes;
+  const long long total = (long long)c->B * c->cap;
+  hipLaunchKernelGGL(export_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, c->d_ids, c->d_xy, c->d_age,
+                     c->d_n, c->cap, total, reinterpret_cast<TrackRecord*>(mine));
+  HIPCHK(c, hipGetLastError());
+  if (nranks > 1) {
+    const RcclApi* a = rccl_api();
+    if (!a || !comm->comm) return fail(c, VSF_E_HIP, "no RCCL communicator: %s", g_comm_err);
+    const ncclResult_t r = a->all_gather(mine, d_recv, bytes, ncclUint8, comm->comm, s);
+    if (r != ncclSuccess) return fail(c, VSF_E_HIP, "ncclAllGather: %s", a->get_error_string(r));
+  }
   return VSF_OK;
 }
 

@@ -1202,6 +1202,53 @@ __global__ __launch_bounds__(256) void table_pack_kernel(const uint64_t* __restr
   }
 }
 
+// cv::cvtColor(BGR2GRAY) on 8-bit interleaved frames of 3 or 4 channels (what both detectors do to a multi-channel
+// frame, FeatureDetectorShiTomasiBucketing.cpp:105-110, FeatureDetectorANMS.cpp:98-99): cv's fixed-point weights, (1868 B + 9617 G + 4899 R +
+// 2^13) >> 14.  Four pixels per thread, one dword store; z = stream.  HBM-bound (cn bytes read, one written).
+__global__ __launch_bounds__(256) void bgr2gray_kernel(const uint8_t* __restrict__ src, long long src_sstride,
+                                                       int src_pitch, int cn, int w, int h,
+                                                       uint8_t* __restrict__ dst, long long dst_sstride, int dst_pitch) {
+  const int x4 = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, y = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (x4 >= w || y >= h) return;
+  const uint8_t* s = src + (long long)blockIdx.z * src_sstride + (long long)y * src_pitch + (long long)x4 * cn;
+  uint8_t* d = dst + (long long)blockIdx.z * dst_sstride + (long long)y * dst_pitch + x4;
+  unsigned int g[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int k = 0; k < 4; k++)
+    if (x4 + k < w) g[k] = ((unsigned int)s[k * cn] * 1868u + (unsigned int)s[k * cn + 1] * 9617u +
+                            (unsigned int)s[k * cn + 2] * 4899u + (1u << 13)) >> 14;
+  if (x4 + 3 < w && ((reinterpret_cast<uintptr_t>(d) & 3) == 0)) {
+    *reinterpret_cast<unsigned int*>(d) = g[0] | (g[1] << 8) | (g[2] << 16) | (g[3] << 24);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (x4 + k < w) d[k] = (uint8_t)g[k];
+  }
+}
+
+// Shader-clock probe (diagnostic, bench.py): one lane spins for `spin_ticks` of the constant-rate counter
+// (s_memrealtime, hipDeviceAttributeWallClockRate) and reports how far the shader cycle counter (s_memtime)
+// moved meanwhile.  Run on a second stream while the step's kernels run, it gives the clock the chip actually
+// holds under that load (DVFS), which the VALU issue figures of DESIGN.md section 5 are stated in.  The loop is
+// bounded by an iteration count as well, so the wave ends whatever the counters do.
+__global__ __launch_bounds__(64) void sclk_probe_kernel(unsigned long long* __restrict__ out,
+                                                        unsigned long long spin_ticks) {
+  if (threadIdx.x != 0) return;
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  unsigned int n = 0;
+  while (r1 - r0 < spin_ticks && n < (1u << 28)) {
+    __builtin_amdgcn_s_sleep(8);
+    r1 = __builtin_amdgcn_s_memrealtime();
+    n++;
+  }
+  const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+  out[0] = t1 - t0;
+  out[1] = r1 - r0;
+  out[2] = n;
+}
+
 // Fixed-size track records for the end-of-step collective over xGMI: 24 bytes,
 // padded to the table capacity so every rank contributes the same byte count.
 struct TrackRecord {

@@ -47,17 +47,21 @@ using FeatureAgeDatabase = std::unordered_map<database_index_t, uint32_t>;
 
 namespace feature {
 
-// What a single-channel 8-bit cv::Mat provides: data, cols, rows, step.
+// What an 8-bit cv::Mat provides: data, cols, rows, step, channels.  The detectors take 1 channel, or 3 / 4
+// interleaved (BGR / BGRA), which they convert like the reference does (cv::cvtColor CV_BGR2GRAY,
+// FeatureDetectorShiTomasiBucketing.cpp:105-110); the trackers take 1 channel.
 struct ImageView {
   const uint8_t* data = nullptr;
   int cols = 0, rows = 0;
   int step = 0;
+  int channels = 1;
   ImageView() = default;
-  ImageView(const uint8_t* d, int c, int r, int s = 0) : data(d), cols(c), rows(r), step(s ? s : c) {}
+  ImageView(const uint8_t* d, int c, int r, int s = 0, int cn = 1)
+      : data(d), cols(c), rows(r), step(s ? s : c * cn), channels(cn) {}
   bool empty() const { return data == nullptr || cols == 0 || rows == 0; }
 #ifdef VSF_WITH_OPENCV
-  ImageView(const cv::Mat& m) : data(m.data), cols(m.cols), rows(m.rows), step((int)m.step) {  // NOLINT
-    if (!m.empty() && m.type() != CV_8UC1) throw std::runtime_error("vsf: CV_8UC1 image expected");
+  ImageView(const cv::Mat& m) : data(m.data), cols(m.cols), rows(m.rows), step((int)m.step), channels(m.channels()) {  // NOLINT
+    if (!m.empty() && m.depth() != CV_8U) throw std::runtime_error("vsf: 8-bit image expected");
   }
 #endif
 };
@@ -132,9 +136,14 @@ class FeatureDetectorShiTomasiBucketing : public FeatureDetectorBase {
     detail::flatten(feature_position, feature_age, capacity_, ids, xy, ag);
     int32_t n = (int32_t)feature_position.size();
     detail::check(ctx_.get(),
-                  vsf_detect(ctx_.get(), current_image.data, current_image.cols, current_image.rows,
-                             current_image.step, mask_image.empty() ? nullptr : mask_image.data, mask_image.step,
-                             ids.data(), xy.data(), ag.data(), &n, (int32_t)capacity_),
+                  current_image.channels == 1
+                      ? vsf_detect(ctx_.get(), current_image.data, current_image.cols, current_image.rows,
+                                   current_image.step, mask_image.empty() ? nullptr : mask_image.data, mask_image.step,
+                                   ids.data(), xy.data(), ag.data(), &n, (int32_t)capacity_)
+                      : vsf_detect_bgr(ctx_.get(), current_image.data, current_image.cols, current_image.rows,
+                                       current_image.step, current_image.channels,
+                                       mask_image.empty() ? nullptr : mask_image.data, mask_image.step, ids.data(),
+                                       xy.data(), ag.data(), &n, (int32_t)capacity_),
                   "UpdateDetection");
     detail::unflatten(ids, xy, ag, n, feature_position, feature_age);
   }
@@ -222,9 +231,14 @@ class FeatureDetectorANMS : public FeatureDetectorBase {
     detail::flatten(feature_position, feature_age, capacity_, ids, xy, ag);
     int32_t n = (int32_t)feature_position.size();
     detail::check(ctx_.get(),
-                  vsf_detect(ctx_.get(), current_image.data, current_image.cols, current_image.rows,
-                             current_image.step, mask_image.empty() ? nullptr : mask_image.data, mask_image.step,
-                             ids.data(), xy.data(), ag.data(), &n, (int32_t)capacity_),
+                  current_image.channels == 1
+                      ? vsf_detect(ctx_.get(), current_image.data, current_image.cols, current_image.rows,
+                                   current_image.step, mask_image.empty() ? nullptr : mask_image.data, mask_image.step,
+                                   ids.data(), xy.data(), ag.data(), &n, (int32_t)capacity_)
+                      : vsf_detect_bgr(ctx_.get(), current_image.data, current_image.cols, current_image.rows,
+                                       current_image.step, current_image.channels,
+                                       mask_image.empty() ? nullptr : mask_image.data, mask_image.step, ids.data(),
+                                       xy.data(), ag.data(), &n, (int32_t)capacity_),
                   "UpdateDetection");
     detail::unflatten(ids, xy, ag, n, feature_position, feature_age);
   }
