@@ -121,8 +121,15 @@ __device__ __forceinline__ void to_sgpr4(int a, int b, int c, int d, int& sa, in
 // Accumulate half: DPP steps, then lane 0 stores and one lane of every 2^NRAW adds (ds_add_u64) into acc[0..N).
 // Nothing is read back here; the reader (this wave or, in the four-wave kernel, the solver wave after a
 // workgroup barrier) finds the exact 64-bit totals in acc.
+// ONE asm statement per group of sums: lane 0 stores its partial, one lane of every 2^NRAW adds (ds_add_u64), every
+// lane reads the totals back.  The three phases differ only in the exec mask, which the statement sets by hand from
+// two constants (as three C++ regions each phase cost a v_mov of the LDS address, an s_and_saveexec / s_or pair and a
+// branch around it -- vector and scalar instructions this kernel is short of).  LDS operations of one wave execute in
+// issue order, so no wait separates the phases.  The wave runs this with every lane active (wave-uniform control
+// flow, 64 threads per workgroup); exec is restored to all ones.
 template <int N, int NRAW>
-__device__ __forceinline__ void wave_sums_to_lds(const int (&p)[N], long long* acc, int lane) {
+__device__ __forceinline__ void wave_sums_lds_roundtrip(const int (&p)[N], long long (&t)[N], long long* acc) {
+  static_assert(N == 2 || N == 3, "two or three sums");
   int q[N];
 #pragma unroll
   for (int i = 0; i < N; i++) q[i] = p[i] + __builtin_amdgcn_update_dpp(0, p[i], 0xB1, 0xf, 0xf, false);
@@ -132,36 +139,48 @@ __device__ __forceinline__ void wave_sums_to_lds(const int (&p)[N], long long* a
 #pragma unroll
     for (int i = 0; i < N; i++) q[i] += __builtin_amdgcn_update_dpp(0, q[i], 0x141, 0xf, 0xf, false);
   }
-  constexpr int LM = (1 << NRAW) - 1;
-  // LDS byte address of the accumulators.  The steps are written as inline asm: left to the compiler, the
-  // atomic is "optimised" into a serial v_readlane loop over the active lanes, which is exactly the VALU
-  // work this routine exists to avoid.
   const unsigned int a32 = (unsigned int)(size_t)(__attribute__((address_space(3))) void*)acc;
-  static_assert(N == 2 || N == 3, "two or three sums");
   long long q64[N];
 #pragma unroll
   for (int i = 0; i < N; i++) q64[i] = (long long)q[i];
-  if (lane == 0) {
-    if constexpr (N == 2)
-      asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8" ::"v"(a32), "v"(q64[0]), "v"(q64[1])
-                   : "memory");
-    else
-      asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:8\n\tds_write_b64 %0, %3 offset:16" ::"v"(a32),
-                   "v"(q64[0]), "v"(q64[1]), "v"(q64[N - 1])
-                   : "memory");
+  // adders: one lane of every 2^NRAW, lane 0 excepted (it stores)
+  constexpr unsigned int ADD_LO = NRAW == 3 ? 0x01010100u : 0x11111110u, ADD_HI = NRAW == 3 ? 0x01010101u : 0x11111111u;
+  if constexpr (N == 2) {
+    asm volatile(
+        "s_mov_b64 exec, 1\n\t"
+        "ds_write_b64 %2, %3\n\t"
+        "ds_write_b64 %2, %4 offset:8\n\t"
+        "s_mov_b32 exec_lo, %5\n\t"
+        "s_mov_b32 exec_hi, %6\n\t"
+        "ds_add_u64 %2, %3\n\t"
+        "ds_add_u64 %2, %4 offset:8\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "ds_read_b64 %0, %2\n\t"
+        "ds_read_b64 %1, %2 offset:8\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(t[0]), "=&v"(t[1])
+        : "v"(a32), "v"(q64[0]), "v"(q64[1]), "s"(ADD_LO), "s"(ADD_HI)
+        : "memory");
+  } else {
+    asm volatile(
+        "s_mov_b64 exec, 1\n\t"
+        "ds_write_b64 %3, %4\n\t"
+        "ds_write_b64 %3, %5 offset:8\n\t"
+        "ds_write_b64 %3, %6 offset:16\n\t"
+        "s_mov_b32 exec_lo, %7\n\t"
+        "s_mov_b32 exec_hi, %8\n\t"
+        "ds_add_u64 %3, %4\n\t"
+        "ds_add_u64 %3, %5 offset:8\n\t"
+        "ds_add_u64 %3, %6 offset:16\n\t"
+        "s_mov_b64 exec, -1\n\t"
+        "ds_read_b64 %0, %3\n\t"
+        "ds_read_b64 %1, %3 offset:8\n\t"
+        "ds_read_b64 %2, %3 offset:16\n\t"
+        "s_waitcnt lgkmcnt(0)"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[N - 1])
+        : "v"(a32), "v"(q64[0]), "v"(q64[1]), "v"(q64[N - 1]), "s"(ADD_LO), "s"(ADD_HI)
+        : "memory");
   }
-  // convergent barriers keep the store, the adds and the loads in this order in the instruction
-  // stream (per lane they are mutually exclusive, so nothing else orders them for the compiler)
-  __builtin_amdgcn_wave_barrier();
-  if (lane != 0 && (lane & LM) == 0) {
-    if constexpr (N == 2)
-      asm volatile("ds_add_u64 %0, %1\n\tds_add_u64 %0, %2 offset:8" ::"v"(a32), "v"(q64[0]), "v"(q64[1]) : "memory");
-    else
-      asm volatile("ds_add_u64 %0, %1\n\tds_add_u64 %0, %2 offset:8\n\tds_add_u64 %0, %3 offset:16" ::"v"(a32),
-                   "v"(q64[0]), "v"(q64[1]), "v"(q64[N - 1])
-                   : "memory");
-  }
-  __builtin_amdgcn_wave_barrier();
 }
 
 // float32 of an exact 64-bit integer total, ONE rounding: v_cvt_f32_i32 when it fits 32 bits, through double otherwise
@@ -170,35 +189,52 @@ __device__ __forceinline__ float exact_i64_to_f32(int lo, int hi) {
   return (float)((double)hi * 4294967296.0 + (double)(unsigned int)lo);
 }
 
+// Totals as scalars: low words in lo[], and `wide` != 0 when some total does not fit 32 bits (hi != sign of lo).  The
+// totals arrive from the LDS (no vector write precedes the lane reads, so no wait state), and the scalar test puts
+// more than two instructions between the lane reads and any later vector use of lo[].
+__device__ __forceinline__ void sums_to_scalars2(const long long (&t)[2], int (&lo)[2], int (&hi)[2], int& wide) {
+  int x0, x1;
+  asm volatile(
+      "v_readfirstlane_b32 %0, %7\n\t"
+      "v_readfirstlane_b32 %1, %8\n\t"
+      "v_readfirstlane_b32 %2, %9\n\t"
+      "v_readfirstlane_b32 %3, %10\n\t"
+      "s_ashr_i32 %5, %0, 31\n\t"
+      "s_ashr_i32 %6, %2, 31\n\t"
+      "s_xor_b32 %5, %5, %1\n\t"
+      "s_xor_b32 %6, %6, %3\n\t"
+      "s_or_b32 %4, %5, %6"
+      : "=&s"(lo[0]), "=&s"(hi[0]), "=&s"(lo[1]), "=&s"(hi[1]), "=&s"(wide), "=&s"(x0), "=&s"(x1)
+      : "v"((int)(unsigned int)(unsigned long long)t[0]), "v"((int)(t[0] >> 32)),
+        "v"((int)(unsigned int)(unsigned long long)t[1]), "v"((int)(t[1] >> 32))
+      : "scc");
+}
+
 template <int N, int NRAW>
 __device__ __forceinline__ void wave_sums_exact_lds(const int (&p)[N], float (&out)[N], long long* acc, int lane) {
-  wave_sums_to_lds<N, NRAW>(p, acc, lane);
-  const unsigned int a32 = (unsigned int)(size_t)(__attribute__((address_space(3))) void*)acc;
+  (void)lane;
   long long t[N];
+  wave_sums_lds_roundtrip<N, NRAW>(p, t, acc);
   if constexpr (N == 2) {
-    asm volatile("ds_read_b64 %0, %2\n\tds_read_b64 %1, %2 offset:8\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(t[0]), "=&v"(t[1])
-                 : "v"(a32)
-                 : "memory");
+    int lo[2], hi[2], wide;
+    sums_to_scalars2(t, lo, hi, wide);
+    if (wide == 0) {  // the common case: both totals fit 32 bits, v_cvt_f32_i32 rounds once
+      out[0] = (float)lo[0];
+      out[1] = (float)lo[1];
+    } else {
+      asm volatile("");  // a block of its own (rare)
+      out[0] = exact_i64_to_f32(lo[0], hi[0]);
+      out[1] = exact_i64_to_f32(lo[1], hi[1]);
+    }
   } else {
-    asm volatile(
-        "ds_read_b64 %0, %3\n\tds_read_b64 %1, %3 offset:8\n\tds_read_b64 %2, %3 offset:16\n\ts_waitcnt lgkmcnt(0)"
-        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[N - 1])
-        : "v"(a32)
-        : "memory");
-  }
-  int los[N], his[N];
-  if constexpr (N == 2) {
-    to_sgpr4((int)(unsigned int)(unsigned long long)t[0], (int)(t[0] >> 32), (int)(unsigned int)(unsigned long long)t[1],
-             (int)(t[1] >> 32), los[0], his[0], los[1], his[1]);
-  } else {
+    int los[N], his[N];
     to_sgpr4((int)(unsigned int)(unsigned long long)t[0], (int)(t[0] >> 32), (int)(unsigned int)(unsigned long long)t[1],
              (int)(t[1] >> 32), los[0], his[0], los[1], his[1]);
     to_sgpr2((int)(unsigned int)(unsigned long long)t[N - 1], (int)(t[N - 1] >> 32), los[N - 1], his[N - 1]);
-  }
-  // scalar from here on: the range test and the recombination cost no vector instruction
+    // scalar from here on: the range test and the recombination cost no vector instruction
 #pragma unroll
-  for (int i = 0; i < N; i++) out[i] = exact_i64_to_f32(los[i], his[i]);
+    for (int i = 0; i < N; i++) out[i] = exact_i64_to_f32(los[i], his[i]);
+  }
 }
 
 // The four weights of a wave-uniform sub-pixel offset, as scalars.  cvRound(x * 2^14), x in [0, 1]:
@@ -215,6 +251,32 @@ __device__ __forceinline__ void bilinear_weights_uniform(float a, float b, int& 
   w01 = s01 - 0x4B400000;
   w10 = s10 - 0x4B400000;
   w11 = (1 << W_BITS) - w00 - w01 - w10;
+}
+
+// The iterations' form: the two packed operands the dot2 instructions take, W0 = w00 | w01 << 16 and
+// W1 = w10 | w11 << 16, as scalars.  Lane reads and scalar arithmetic in ONE statement: the low 16 bits of the
+// biased floats ARE the weights (0x4B400000 has none), s_pack_ll_b32_b16 joins two of them, and
+// w11 = 2^14 - w00 - w01 - w10 = 0xE1C04000 - (s00 + s01 + s10) mod 2^32 (it may be -1; the dot2 is signed).
+// No trailing wait state: five scalar instructions separate the lane reads from any vector use of the results.
+__device__ __forceinline__ void bilinear_weights_packed(float a, float b, unsigned int& W0, unsigned int& W1) {
+  const float MAGIC = 12582912.f;  // 1.5 * 2^23
+  const float a1 = 1.f - a;
+  const float b1 = (1.f - b) * (float)(1 << W_BITS), b0 = b * (float)(1 << W_BITS);
+  const float p00 = a1 * b1 + MAGIC, p01 = a * b1 + MAGIC, p10 = a1 * b0 + MAGIC;
+  unsigned int t0, t1, t2;
+  asm volatile(
+      "s_nop 0\n\t"
+      "v_readfirstlane_b32 %2, %5\n\t"
+      "v_readfirstlane_b32 %3, %6\n\t"
+      "v_readfirstlane_b32 %4, %7\n\t"
+      "s_pack_ll_b32_b16 %0, %2, %3\n\t"
+      "s_add_i32 %2, %2, %3\n\t"
+      "s_add_i32 %2, %2, %4\n\t"
+      "s_sub_i32 %2, 0xe1c04000, %2\n\t"
+      "s_pack_ll_b32_b16 %1, %4, %2"
+      : "=&s"(W0), "=&s"(W1), "=&s"(t0), "=&s"(t1), "=&s"(t2)
+      : "v"(p00), "v"(p01), "v"(p10)
+      : "scc");
 }
 
 __device__ __forceinline__ void bilinear_weights(float a, float b, int& w00, int& w01, int& w10, int& w11) {
@@ -237,6 +299,43 @@ __device__ __forceinline__ int sdot2(unsigned int a, unsigned int b, int c) {
 // (lo & 0xffff) | (hi << 16) in one v_perm_b32
 __device__ __forceinline__ unsigned int pack_lo16(int lo, int hi) {
   return __builtin_amdgcn_perm((unsigned int)hi, (unsigned int)lo, 0x05040100u);
+}
+
+// The same as a THREE-operand instruction (v_dot2_i32_i16, VOP3P): the compiler only ever selects the two-operand
+// v_dot2c_i32_i16 for the builtin and copies the accumulator first when it is still needed (or is a constant).
+// First link of an accumulation chain that starts from a live value or from zero: no v_mov.
+__device__ __forceinline__ int sdot2_acc(unsigned int a, unsigned int b, int c) {
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+// first link of a bilinear sample: pixel pair (VGPR) x packed weights (SGPR) + rounding constant (VGPR)
+__device__ __forceinline__ int sdot2_sw(unsigned int px, unsigned int w_uniform, int c) {
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(px), "s"(w_uniform), "v"(c));
+  return r;
+}
+__device__ __forceinline__ int sdot2_zero(unsigned int a, unsigned int b) {
+  int r;
+  asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// ((lo >> SH) & 0xffff) | ((hi >> SH) << 16) for values whose shifted form fits 16 bits (signed or not): a shift,
+// then a shift that writes the upper word of the same register (SDWA) -- two instructions instead of two shifts
+// and a v_perm.
+template <int SH>
+__device__ __forceinline__ unsigned int pack_shr16(int lo, int hi) {
+  unsigned int r = (unsigned int)(lo >> SH) & 0xffffu;
+  asm("v_ashrrev_i32_sdwa %0, %1, %2 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD"
+      : "+v"(r)
+      : "n"(SH), "v"(hi));
+  return r;
+}
+// the odd last pixel of a lane: (lo >> SH) & 0xffff
+template <int SH>
+__device__ __forceinline__ unsigned int pack_shr16_single(int lo) {
+  return (unsigned int)(lo >> SH) & 0xffffu;
 }
 
 // Reads NA+... dwords of an LDS byte row starting at byte offset `boff` and returns, in A[], the byte
@@ -285,39 +384,29 @@ __device__ __forceinline__ unsigned int byte_pair(const unsigned int (&A)[NA]) {
 template <int K, int N, int NA, int C0>
 struct BilinearRow {
   // out[k] = C0 + sum over the 2x2 neighbourhood, for k = K..N-1 (compile-time recursion keeps every
-  // index a constant, so the arrays stay in registers).  C0 carries DESCALE's rounding constant.
+  // index a constant, so the arrays stay in registers).  C0 carries DESCALE's rounding constant.  Signed dot2 for
+  // every weight set (w11 may be -1): the first link is the three-operand form on a register that holds C0 (the
+  // two-operand form the compiler selects copies the constant into every pixel's accumulator first), the second
+  // accumulates in place.  W0, W1 wave-uniform.
   static __device__ __forceinline__ void run(const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
-                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
-    out[K] = sdot2(byte_pair<K, NA>(A1), W1, sdot2(byte_pair<K, NA>(A0), W0, C0));
-    if constexpr (K + 1 < N) BilinearRow<K + 1, N, NA, C0>::run(A0, A1, W0, W1, out);
+                                             unsigned int W0, unsigned int W1, int c0, int (&out)[N]) {
+    out[K] = sdot2(byte_pair<K, NA>(A1), W1, sdot2_sw(byte_pair<K, NA>(A0), W0, c0));
+    if constexpr (K + 1 < N) BilinearRow<K + 1, N, NA, C0>::run(A0, A1, W0, W1, c0, out);
   }
 };
+
+template <int N, int NA, int C0>
+__device__ __forceinline__ void bilinear_row(const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
+                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
+  int c0 = C0;
+  asm("" : "+v"(c0));  // one register for the whole row, not a literal per pixel
+  BilinearRow<0, N, NA, C0>::run(A0, A1, W0, W1, c0, out);
+}
 
 typedef unsigned short vsf_u16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ int udot2(unsigned int a, unsigned int b, int c) {
   return (int)__builtin_amdgcn_udot2(__builtin_bit_cast(vsf_u16x2, a), __builtin_bit_cast(vsf_u16x2, b),
                                      (unsigned int)c, false);
-}
-
-// Unsigned twin of BilinearRow for the common case of four non-negative weights: v_dot2_u32_u16 is a
-// three-operand instruction, so the accumulator constant needs no v_mov per pixel (the signed form
-// on gfx950 is the two-operand v_dot2c_i32_i16).
-template <int K, int N, int NA, int C0>
-struct BilinearRowU {
-  static __device__ __forceinline__ void run(const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
-                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
-    out[K] = udot2(byte_pair<K, NA>(A1), W1, udot2(byte_pair<K, NA>(A0), W0, C0));
-    if constexpr (K + 1 < N) BilinearRowU<K + 1, N, NA, C0>::run(A0, A1, W0, W1, out);
-  }
-};
-
-template <int N, int NA, int C0>
-__device__ __forceinline__ void bilinear_row(bool nonneg, const unsigned int (&A0)[NA], const unsigned int (&A1)[NA],
-                                             unsigned int W0, unsigned int W1, int (&out)[N]) {
-  if (nonneg)
-    BilinearRowU<0, N, NA, C0>::run(A0, A1, W0, W1, out);
-  else
-    BilinearRow<0, N, NA, C0>::run(A0, A1, W0, W1, out);
 }
 
 // LDS carve-up per wave and the geometry of the two staged regions
@@ -557,12 +646,12 @@ __device__ __forceinline__ void lk_stage_i(const PyrView& A, int level, int stre
 
 // The template of a level from the staged I patch: interpolated intensities and Scharr gradients of the lane's
 // pixels.  Out: gradients pair-packed (IxP[k2] = Ix[2k2] | Ix[2k2+1] << 16, zero where the lane owns no pixel), the
-// lane's share of sum I*Ix, sum I*Iy (cI1, cI2) and of A11, A12, A22 (part).  All weights wave-uniform.
+// lane's share of -sum I*Ix, -sum I*Iy (ncI1, ncI2) and of A11, A12, A22 (part).  All weights wave-uniform.
 template <int SEG>
 __device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, const LkParams& prm, const LkLaneMap& m,
                                             int lane, int aw, int ah, int ipx, int ipy, bool interior, int iw00,
                                             int iw01, int iw10, int iw11, unsigned int (&IxP)[(SEG + 1) / 2],
-                                            unsigned int (&IyP)[(SEG + 1) / 2], int& cI1, int& cI2, int (&part)[3]) {
+                                            unsigned int (&IyP)[(SEG + 1) / 2], int& ncI1, int& ncI2, int (&part)[3]) {
   constexpr int NA = (SEG + 1 + 3) / 4;  // aligned dwords holding SEG+1 bytes
   constexpr int NP = (SEG + 1) / 2;      // pixel pairs per lane
   const int win = prm.win;
@@ -570,8 +659,7 @@ __device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, cons
   int* sD = reinterpret_cast<int*>(smem + L.off_d);
   const int oI = (ipx - 1) - ((ipx - 1) & ~3);
   const int rowI = m.rowI, rr = m.rr, xx0 = m.xx0;
-  int Iw[SEG + 1];
-  Iw[SEG] = 0;
+  unsigned int IwP[NP];
   const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
   const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
   unsigned int pm[NP];
@@ -587,46 +675,58 @@ __device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, cons
     // The three V rows are produced one after the other and folded into the vertical Scharr sums
     // at once (T0 = 3 V0 + 10 V1 + 3 V2, T1 = V2 - V0), so at most one V row is live.
     const uint8_t* rI = sI + rowI;
-    const bool wpos = iw11 >= 0;  // the other three weights are rounded products of non-negatives
     int T0[NC], T1[NC];
     {
       unsigned int Ra[NAV], Rb[NAV];
       int V[NC];
       lds_stream<NAV>(rI, oI + xx0, Ra);
       lds_stream<NAV>(rI + L.gi.pitch, oI + xx0, Rb);
-      bilinear_row<NC, NAV, 0>(wpos, Ra, Rb, W0, W1, V);  // V0
+      bilinear_row<NC, NAV, 0>(Ra, Rb, W0, W1, V);  // V0
 #pragma unroll
       for (int c = 0; c < NC; c++) {
         T0[c] = __mul24(V[c], 3);
         T1[c] = -V[c];
       }
       lds_stream<NAV>(rI + 2 * L.gi.pitch, oI + xx0, Ra);
-      bilinear_row<NC, NAV, 0>(wpos, Rb, Ra, W0, W1, V);  // V1
+      bilinear_row<NC, NAV, 0>(Rb, Ra, W0, W1, V);  // V1
 #pragma unroll
       for (int c = 0; c < NC; c++) T0[c] += __mul24(V[c], 10);
+      {
+        int Ir[SEG + 1];  // DESCALE's rounding constant added here, the shift happens in the pack
+        Ir[SEG] = 0;
 #pragma unroll
-      for (int k = 0; k < SEG; k++) Iw[k] = VSF_DESCALE(V[k + 1], W_BITS - 5);
+        for (int k = 0; k < SEG; k++) Ir[k] = V[k + 1] + (1 << (W_BITS - 5 - 1));
+#pragma unroll
+        for (int k2 = 0; k2 < NP; k2++)
+          IwP[k2] = (2 * k2 + 1 < SEG) ? pack_shr16<W_BITS - 5>(Ir[2 * k2], Ir[2 * k2 + 1])
+                                       : pack_shr16_single<W_BITS - 5>(Ir[2 * k2]);
+      }
       lds_stream<NAV>(rI + 3 * L.gi.pitch, oI + xx0, Rb);
-      bilinear_row<NC, NAV, 0>(wpos, Ra, Rb, W0, W1, V);  // V2
+      bilinear_row<NC, NAV, 0>(Ra, Rb, W0, W1, V);  // V2
 #pragma unroll
       for (int c = 0; c < NC; c++) {
         T0[c] += __mul24(V[c], 3);  // < 2^27
         T1[c] += V[c];
       }
     }
-    int ixv[SEG + 1], iyv[SEG + 1];
-    ixv[SEG] = 0;
-    iyv[SEG] = 0;
+    int ixr[SEG + 1], iyr[SEG + 1];  // before DESCALE's shift (the pack shifts)
+    ixr[SEG] = 0;
+    iyr[SEG] = 0;
 #pragma unroll
     for (int k = 0; k < SEG; k++) {
-      ixv[k] = VSF_DESCALE(T0[k + 2] - T0[k], W_BITS);
-      iyv[k] = VSF_DESCALE(3 * (T1[k] + T1[k + 2]) + 10 * T1[k + 1], W_BITS);
+      ixr[k] = T0[k + 2] - T0[k] + (1 << (W_BITS - 1));
+      iyr[k] = 3 * (T1[k] + T1[k + 2]) + 10 * T1[k + 1] + (1 << (W_BITS - 1));
     }
     // pixels a lane does not own carry zero gradients, so they add nothing to any sum
 #pragma unroll
     for (int k2 = 0; k2 < NP; k2++) {
-      IxP[k2] = pack_lo16(ixv[2 * k2], ixv[2 * k2 + 1]) & pm[k2];
-      IyP[k2] = pack_lo16(iyv[2 * k2], iyv[2 * k2 + 1]) & pm[k2];
+      if (2 * k2 + 1 < SEG) {
+        IxP[k2] = pack_shr16<W_BITS>(ixr[2 * k2], ixr[2 * k2 + 1]) & pm[k2];
+        IyP[k2] = pack_shr16<W_BITS>(iyr[2 * k2], iyr[2 * k2 + 1]) & pm[k2];
+      } else {
+        IxP[k2] = pack_shr16_single<W_BITS>(ixr[2 * k2]) & pm[k2];
+        IyP[k2] = pack_shr16_single<W_BITS>(iyr[2 * k2]) & pm[k2];
+      }
     }
   } else {
     // Generic path (window touches the level border): Scharr gradient patch (win+1)^2 in LDS,
@@ -664,7 +764,7 @@ __device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, cons
     lds_stream<NA>(sI + rowI + L.gi.pitch, oI + 1 + xx0, R0);
     lds_stream<NA>(sI + rowI + 2 * L.gi.pitch, oI + 1 + xx0, R1);
     int Iv[SEG];
-    BilinearRow<0, SEG, NA, (1 << (W_BITS - 5 - 1))>::run(R0, R1, W0, W1, Iv);
+    bilinear_row<SEG, NA, (1 << (W_BITS - 5 - 1))>(R0, R1, W0, W1, Iv);
     const int* d0 = sD + rr * L.d_pitch + xx0;
     const int* d1 = d0 + L.d_pitch;
     int ixv[SEG + 1], iyv[SEG + 1];
@@ -672,7 +772,6 @@ __device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, cons
     iyv[SEG] = 0;
 #pragma unroll
     for (int k = 0; k < SEG; k++) {
-      Iw[k] = Iv[k] >> (W_BITS - 5);
       ixv[k] = 0;
       iyv[k] = 0;
       if (k < prm.seglen) {  // d0[k + 1] stays inside the (win+1)-wide patch for every pixel read
@@ -691,22 +790,38 @@ __device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, cons
       IxP[k2] = pack_lo16(ixv[2 * k2], ixv[2 * k2 + 1]) & pm[k2];
       IyP[k2] = pack_lo16(iyv[2 * k2], iyv[2 * k2 + 1]) & pm[k2];
     }
+    {
+      int Iw[SEG + 1];
+      Iw[SEG] = 0;
+#pragma unroll
+      for (int k = 0; k < SEG; k++) Iw[k] = Iv[k] >> (W_BITS - 5);
+#pragma unroll
+      for (int k2 = 0; k2 < NP; k2++) IwP[k2] = pack_lo16(Iw[2 * k2], Iw[2 * k2 + 1]);
+    }
     lk_wave_sync();  // the gradient patch shares its space with the J region: reads done before any staging
   }
-  // b = sum (Jw - Iw) * (Ix, Iy) = sum Jw * (Ix, Iy) - (cI1, cI2): the template's own part is a
-  // per-lane constant of the level, so the iterations neither subtract per pixel nor keep Iw live
-  int a11 = 0, a12 = 0, a22 = 0;
-  cI1 = 0;
-  cI2 = 0;
+  // b = sum (Jw - Iw) * (Ix, Iy) = sum Jw * (Ix, Iy) + (ncI1, ncI2): the template's own part is a per-lane constant of
+  // the level (kept NEGATED: the iterations' accumulation chains start from it), so the iterations neither subtract
+  // per pixel nor keep Iw live.  IwP[k2] = Iw[2 k2] | Iw[2 k2 + 1] << 16, 0 <= Iw <= 8160.
+  int a11 = 0, a12 = 0, a22 = 0, c1 = 0, c2 = 0;
 #pragma unroll
   for (int k2 = 0; k2 < NP; k2++) {
-    const unsigned int iwp = pack_lo16(Iw[2 * k2], Iw[2 * k2 + 1]);  // 0 <= Iw <= 8160
-    a11 = sdot2(IxP[k2], IxP[k2], a11);
-    a12 = sdot2(IxP[k2], IyP[k2], a12);
-    a22 = sdot2(IyP[k2], IyP[k2], a22);
-    cI1 = sdot2(iwp, IxP[k2], cI1);
-    cI2 = sdot2(iwp, IyP[k2], cI2);
+    if (k2 == 0) {
+      a11 = sdot2_zero(IxP[0], IxP[0]);
+      a12 = sdot2_zero(IxP[0], IyP[0]);
+      a22 = sdot2_zero(IyP[0], IyP[0]);
+      c1 = sdot2_zero(IwP[0], IxP[0]);
+      c2 = sdot2_zero(IwP[0], IyP[0]);
+    } else {
+      a11 = sdot2(IxP[k2], IxP[k2], a11);
+      a12 = sdot2(IxP[k2], IyP[k2], a12);
+      a22 = sdot2(IyP[k2], IyP[k2], a22);
+      c1 = sdot2(IwP[k2], IxP[k2], c1);
+      c2 = sdot2(IwP[k2], IyP[k2], c2);
+    }
   }
+  ncI1 = -c1;
+  ncI2 = -c2;
   part[0] = a11;
   part[1] = a12;
   part[2] = a22;
@@ -744,41 +859,38 @@ __device__ __forceinline__ void lk_stage_j(const uint8_t* __restrict__ Bb, int b
   }
 }
 
-// One iteration's pixel work: the lane's share of b1 = sum Jw * Ix - cI1, b2 = sum Jw * Iy - cI2, with Jw the
+// One iteration's pixel work: the lane's share of b1 = sum Jw * Ix + ncI1, b2 = sum Jw * Iy + ncI2, with Jw the
 // bilinear sample of J at the lane's pixels.  p0 = the lane's first pixel in the pair region for this window
-// position; V0, V1 = packed weights (w00 | w01 << 16, w10 | w11 << 16); nonneg = (w11 >= 0).
+// position; V0, V1 = packed weights (w00 | w01 << 16, w10 | w11 << 16), wave-uniform.
 template <int SEG>
 __device__ __forceinline__ void lk_iter_pixels(const unsigned int* p0, int jp_pitch, unsigned int V0, unsigned int V1,
-                                               bool nonneg, const unsigned int (&IxP)[(SEG + 1) / 2],
-                                               const unsigned int (&IyP)[(SEG + 1) / 2], int cI1, int cI2, int& b1,
-                                               int& b2) {
+                                               const unsigned int (&IxP)[(SEG + 1) / 2],
+                                               const unsigned int (&IyP)[(SEG + 1) / 2], int ncI1, int ncI2, int c0,
+                                               int& b1, int& b2) {
   constexpr int NP = (SEG + 1) / 2;
   unsigned int R0[SEG], R1[SEG];
 #pragma unroll
   for (int k = 0; k < SEG; k++) R0[k] = p0[k];
 #pragma unroll
   for (int k = 0; k < SEG; k++) R1[k] = p0[jp_pitch + k];
-  int Jw[SEG + 1];
-  Jw[SEG] = 0;
-  {
-    int Jr[SEG];
-    if (nonneg) {
+  // Jw = Jr >> 9 (0 <= Jw <= 8160; Jr > 0 even when w11 = -1), two pixels to a dword: a bit-field extract, then a
+  // shift that writes the upper word (pack_shr16); the accumulation chains open with the three-operand dot2 on the
+  // level's constants ncI1 = -sum I*Ix, ncI2 = -sum I*Iy (this lane's share), so nothing is copied
+  int Jr[SEG + 1];
+  Jr[SEG] = 0;
 #pragma unroll
-      for (int k = 0; k < SEG; k++) Jr[k] = udot2(R1[k], V1, udot2(R0[k], V0, (1 << (W_BITS - 5 - 1))));
-    } else {
-#pragma unroll
-      for (int k = 0; k < SEG; k++) Jr[k] = sdot2(R1[k], V1, sdot2(R0[k], V0, (1 << (W_BITS - 5 - 1))));
-    }
-#pragma unroll
-    for (int k = 0; k < SEG; k++) Jw[k] = Jr[k] >> (W_BITS - 5);  // 0 <= Jw <= 8160
-  }
-  b1 = -cI1;
-  b2 = -cI2;
+  for (int k = 0; k < SEG; k++) Jr[k] = sdot2(R1[k], V1, sdot2_sw(R0[k], V0, c0));  // c0 = DESCALE's rounding constant
 #pragma unroll
   for (int k2 = 0; k2 < NP; k2++) {
-    const unsigned int jp = pack_lo16(Jw[2 * k2], Jw[2 * k2 + 1]);
-    b1 = sdot2(jp, IxP[k2], b1);
-    b2 = sdot2(jp, IyP[k2], b2);
+    const unsigned int jp = (2 * k2 + 1 < SEG) ? pack_shr16<W_BITS - 5>(Jr[2 * k2], Jr[2 * k2 + 1])
+                                               : pack_shr16_single<W_BITS - 5>(Jr[2 * k2]);
+    if (k2 == 0) {
+      b1 = sdot2_acc(jp, IxP[0], ncI1);
+      b2 = sdot2_acc(jp, IyP[0], ncI2);
+    } else {
+      b1 = sdot2(jp, IxP[k2], b1);
+      b2 = sdot2(jp, IyP[k2], b2);
+    }
   }
 }
 
@@ -885,7 +997,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     if (!in_range && level == 0) status = false;
 
     unsigned int IxP[NP], IyP[NP];  // template gradients, pair-packed, zero where the lane owns no pixel
-    int cI1 = 0, cI2 = 0;
+    int ncI1 = 0, ncI2 = 0;  // this lane's share of -sum I*Ix, -sum I*Iy
     float A11 = 0.f, A12 = 0.f, A22 = 0.f, D = 0.f;
     if (level_ok && cached) {
       VSF_LKSTAT(level * 16 + 9);
@@ -897,8 +1009,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         const uint2 ci = reinterpret_cast<const uint2*>(t + 128)[lane];
         IxP[0] = gx.x, IxP[1] = gx.y, IxP[2] = gx.z, IxP[3] = gx.w;
         IyP[0] = gy.x, IyP[1] = gy.y, IyP[2] = gy.z, IyP[3] = gy.w;
-        cI1 = (int)ci.x;
-        cI2 = (int)ci.y;
+        ncI1 = (int)ci.x;
+        ncI2 = (int)ci.y;
         A11 = h.y;
         A12 = h.z;
         A22 = h.w;
@@ -914,7 +1026,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       // every tap of every window pixel lies inside the level image: no zero-padded gradient involved
       const bool interior = ipx >= 0 && ipy >= 0 && ipx + win < aw && ipy + win < ah;
       int part[3];
-      lk_template<SEG>(smem, L, prm, m, lane, aw, ah, ipx, ipy, interior, iw00, iw01, iw10, iw11, IxP, IyP, cI1, cI2,
+      lk_template<SEG>(smem, L, prm, m, lane, aw, ah, ipx, ipy, interior, iw00, iw01, iw10, iw11, IxP, IyP, ncI1, ncI2,
                        part);
       float Asum[3];
 #if VSF_SUM_LDS
@@ -930,7 +1042,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
           uint4* t = tc.wr_tpl + level * LK_TPL_U4;
           t[lane] = make_uint4(IxP[0], IxP[1], IxP[2], IxP[3]);
           t[64 + lane] = make_uint4(IyP[0], IyP[1], IyP[2], IyP[3]);
-          reinterpret_cast<uint2*>(t + 128)[lane] = make_uint2((unsigned int)cI1, (unsigned int)cI2);
+          reinterpret_cast<uint2*>(t + 128)[lane] = make_uint2((unsigned int)ncI1, (unsigned int)ncI2);
           if (lane == 0) tc.wr_hdr[level] = make_float4(__int_as_float(1), A11, A12, A22);
         }
       }
@@ -948,38 +1060,40 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       VSF_LKSTAT(level * 16 + 1);
       int n_iter = 0, end_kind = 7;
       D = 1.f / D;
-      bool staged = false;
       float cx = nx - half, cy = ny - half;  // nextPt - halfWin
       float pdx = 0.f, pdy = 0.f;
+      // inx in [-win, bw) <=> (unsigned)(inx + win) < bw + win; the staged J region covers the window at (inx, iny)
+      // <=> (unsigned)(inx - jx0) <= jxmax and the same in y.  jx0 far away = nothing staged at this level yet.
+      const unsigned int bwW = (unsigned int)(bw + win), bhW = (unsigned int)(bh + win);
+      const unsigned int jxmax = (unsigned int)(4 * L.gj.ndw - win - 1), jymax = (unsigned int)(L.gj.rows - win - 1);
+      jx0 = 0x40000000;
+      int c256 = 1 << (W_BITS - 5 - 1);  // the samples' rounding constant, in a register for the whole level
+      asm volatile("" : "+v"(c256));
       for (int j = 0; j < prm.max_count; j++) {
         const float fcx = floorf(cx), fcy = floorf(cy);
         const int inx = uniform_f2i(fcx);
         const int iny = uniform_f2i(fcy);
-        if (inx < -win || inx >= bw || iny < -win || iny >= bh) {
+        if ((unsigned int)(inx + win) >= bwW || (unsigned int)(iny + win) >= bhW) {
           if (level == 0) status = false;
           end_kind = 8;
           break;
         }
         n_iter++;
-        if (!staged || inx < jx0 || iny < jy0 || inx + win + 1 > jx0 + 4 * L.gj.ndw ||
-            iny + win + 1 > jy0 + L.gj.rows) {
+        if ((unsigned int)(inx - jx0) > jxmax || (unsigned int)(iny - jy0) > jymax) {
           lk_wave_sync();  // previous iteration's reads are done
           jx0 = (inx - prm.jmargin) & ~3;
           jy0 = iny - prm.jmargin;
           lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
-          staged = true;
           VSF_LKSTAT(level * 16 + 3);
           lk_wave_sync();
         }
-        int iw00, iw01, iw10, iw11;
-        bilinear_weights_uniform(cx - fcx, cy - fcy, iw00, iw01, iw10, iw11);
+        unsigned int V0, V1;
+        bilinear_weights_packed(cx - fcx, cy - fcy, V0, V1);
         int b1, b2;
         {
           // rowJ0 = sJ + rr * pitch + xx0 per lane; the rest of the address is wave-uniform
           const unsigned int* p0 = m.rowJ0 + ((iny - jy0) * L.jp_pitch + (inx - jx0));
-          const unsigned int V0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
-          const unsigned int V1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
-          lk_iter_pixels<SEG>(p0, L.jp_pitch, V0, V1, iw11 >= 0, IxP, IyP, cI1, cI2, b1, b2);
+          lk_iter_pixels<SEG>(p0, L.jp_pitch, V0, V1, IxP, IyP, ncI1, ncI2, c256, b1, b2);
         }
         float bsum[2];
         {
