@@ -894,16 +894,40 @@ __device__ __forceinline__ void lk_iter_pixels(const unsigned int* p0, int jp_pi
   }
 }
 
+// Head of an iteration: the window position as scalars and ONE flag for "needs attention" (outside the box of
+// positions that are both in range and served by the staged J region; see lk_track_point).  Lane reads and the
+// two unsigned range tests in one statement: the compiler turns the same tests into two dozen mask instructions.
+__device__ __forceinline__ void lk_iter_head(int vinx, int viny, int lox, int loy, unsigned int nbx, unsigned int nby,
+                                             int& inx, int& iny, int& rare) {
+  int tmp;
+  asm volatile(
+      "s_nop 0\n\t"
+      "v_readfirstlane_b32 %0, %4\n\t"
+      "v_readfirstlane_b32 %1, %5\n\t"
+      "s_sub_i32 %2, %0, %6\n\t"
+      "s_sub_i32 %3, %1, %7\n\t"
+      "s_cmp_le_u32 %2, %8\n\t"
+      "s_cselect_b32 %3, %3, -1\n\t"
+      "s_cmp_le_u32 %3, %9\n\t"
+      "s_cselect_b32 %2, 0, 1"
+      : "=&s"(inx), "=&s"(iny), "=&s"(rare), "=&s"(tmp)
+      : "v"(vinx), "v"(viny), "s"(lox), "s"(loy), "s"(nbx), "s"(nby)
+      : "scc");
+}
+
 // cv: dx*dx + dy*dy <= eps^2 evaluated in double.  The float value s is within 3 ulp of the
 // exact sum, so outside a 1e-6 relative band around eps^2 the float compare already decides.
+// The arguments are wave-uniform values held in vector registers; every decision goes through a ballot, which makes
+// the branch a scalar one in the compiler's eyes too (a branch on a vector compare counts as divergent, and a loop
+// with divergent exits is rebuilt around mask registers: a dozen scalar instructions on every trip).
 __device__ __forceinline__ bool lk_converged(float dx, float dy, const LkParams& prm) {
   const float s = __fmaf_rn(dx, dx, dy * dy);
-  if (s <= prm.eps2_lo) return true;
-  if (s >= prm.eps2_hi) return false;
+  if (__ballot(s <= prm.eps2_lo) != 0ull) return true;
+  if (__ballot(s >= prm.eps2_hi) != 0ull) return false;
   // an empty volatile asm gives the rare block a side effect: it cannot be if-converted into the common path (where
   // its seven double-precision instructions ran in every iteration that did not converge)
   asm volatile("");
-  return (double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2;
+  return __ballot((double)dx * (double)dx + (double)dy * (double)dy <= prm.eps2) != 0ull;
 }
 
 // ---- template cache -------------------------------------------------------------------------------------
@@ -1061,71 +1085,95 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       int n_iter = 0, end_kind = 7;
       D = 1.f / D;
       float cx = nx - half, cy = ny - half;  // nextPt - halfWin
-      float pdx = 0.f, pdy = 0.f;
-      // inx in [-win, bw) <=> (unsigned)(inx + win) < bw + win; the staged J region covers the window at (inx, iny)
-      // <=> (unsigned)(inx - jx0) <= jxmax and the same in y.  jx0 far away = nothing staged at this level yet.
-      const unsigned int bwW = (unsigned int)(bw + win), bhW = (unsigned int)(bh + win);
-      const unsigned int jxmax = (unsigned int)(4 * L.gj.ndw - win - 1), jymax = (unsigned int)(L.gj.rows - win - 1);
-      jx0 = 0x40000000;
+      // cv tests the oscillation rule from the second iteration on (j > 0): a first "previous delta" this large
+      // fails it by itself
+      float pdx = 1e30f, pdy = 1e30f;
+      // An iteration at window position (inx, iny) needs no attention when the position lies inside the level's
+      // range AND inside the staged J region: both in one test against [lox, lox + nx] x [loy, loy + ny], the
+      // intersection of the two, kept as scalars and recomputed when a region is staged.  Outside it (rare) the
+      // position has either left the image or needs a new region.  Nothing staged yet = an empty box far away.
+      int lox = 0x40000000, loy = 0x40000000;
+      unsigned int nbx = 0u, nby = 0u;
       int c256 = 1 << (W_BITS - 5 - 1);  // the samples' rounding constant, in a register for the whole level
       asm volatile("" : "+v"(c256));
-      for (int j = 0; j < prm.max_count; j++) {
+      // One scalar state word steers the loop (0 = keep iterating; else how the level ended: 5 converged, 6 the
+      // oscillation rule, 7 max_count, 8 left the image) and every ending goes through the single latch at the
+      // bottom: with exits from the middle the compiler rebuilds the loop around mask registers (the staging code
+      // inside it has lane-dependent branches) and spends a dozen scalar instructions per trip on them.
+      int state = prm.max_count > 0 ? 0 : 7;
+      int j = 0;
+      while (state == 0) {
         const float fcx = floorf(cx), fcy = floorf(cy);
-        const int inx = uniform_f2i(fcx);
-        const int iny = uniform_f2i(fcy);
-        if ((unsigned int)(inx + win) >= bwW || (unsigned int)(iny + win) >= bhW) {
-          if (level == 0) status = false;
-          end_kind = 8;
-          break;
+        int inx, iny, rare;
+        lk_iter_head((int)fcx, (int)fcy, lox, loy, nbx, nby, inx, iny, rare);
+        if (rare) {
+          asm volatile("");  // a block of its own
+          // cv: in < -win || in >= size  <=>  (unsigned)(in + win) >= size + win
+          if ((unsigned int)(inx + win) >= (unsigned int)(bw + win) || (unsigned int)(iny + win) >= (unsigned int)(bh + win)) {
+            state = 8;
+          } else {
+            lk_wave_sync();  // previous iteration's reads are done
+            jx0 = (inx - prm.jmargin) & ~3;
+            jy0 = iny - prm.jmargin;
+            lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
+            VSF_LKSTAT(level * 16 + 3);
+            lk_wave_sync();
+            // window positions the region serves: jx0 .. jx0 + 4 ndw - win - 1, cut to the level's range -win .. bw - 1
+            lox = max(jx0, -win);
+            loy = max(jy0, -win);
+            nbx = (unsigned int)(min(jx0 + 4 * L.gj.ndw - win - 1, bw - 1) - lox);
+            nby = (unsigned int)(min(jy0 + L.gj.rows - win - 1, bh - 1) - loy);
+          }
         }
-        n_iter++;
-        if ((unsigned int)(inx - jx0) > jxmax || (unsigned int)(iny - jy0) > jymax) {
-          lk_wave_sync();  // previous iteration's reads are done
-          jx0 = (inx - prm.jmargin) & ~3;
-          jy0 = iny - prm.jmargin;
-          lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
-          VSF_LKSTAT(level * 16 + 3);
-          lk_wave_sync();
-        }
-        unsigned int V0, V1;
-        bilinear_weights_packed(cx - fcx, cy - fcy, V0, V1);
-        int b1, b2;
-        {
-          // rowJ0 = sJ + rr * pitch + xx0 per lane; the rest of the address is wave-uniform
-          const unsigned int* p0 = m.rowJ0 + ((iny - jy0) * L.jp_pitch + (inx - jx0));
-          lk_iter_pixels<SEG>(p0, L.jp_pitch, V0, V1, IxP, IyP, ncI1, ncI2, c256, b1, b2);
-        }
-        float bsum[2];
-        {
-          const int part[2] = {b1, b2};
+        if (state == 0) {
+          n_iter++;
+          unsigned int V0, V1;
+          bilinear_weights_packed(cx - fcx, cy - fcy, V0, V1);
+          int b1, b2;
+          {
+            // rowJ0 = sJ + rr * pitch + xx0 per lane; the rest of the address is wave-uniform
+            const unsigned int* p0 = m.rowJ0 + ((iny - jy0) * L.jp_pitch + (inx - jx0));
+            lk_iter_pixels<SEG>(p0, L.jp_pitch, V0, V1, IxP, IyP, ncI1, ncI2, c256, b1, b2);
+          }
+          float bsum[2];
+          {
+            const int part[2] = {b1, b2};
 #if VSF_SUM_LDS
-          wave_sums_exact_lds<2, NRAW>(part, bsum, sAcc, lane);
+            wave_sums_exact_lds<2, NRAW>(part, bsum, sAcc, lane);
 #else
-          wave_sums_exact_f32<2>(part, bsum);
+            wave_sums_exact_f32<2>(part, bsum);
 #endif
+          }
+          const float fb1 = bsum[0] * FLT_SCALE, fb2 = bsum[1] * FLT_SCALE;
+          const float dx = (A12 * fb2 - A22 * fb1) * D;
+          const float dy = (A12 * fb1 - A11 * fb2) * D;
+          cx += dx;
+          cy += dy;
+          nx = cx + half;
+          ny = cy + half;
+          // The common outcome first, in ONE branch: clearly not converged (|delta|^2 at or above the upper edge of
+          // the band around eps^2) and not oscillating.  cv compares |dx + prev| and |dy + prev| with the double
+          // 0.01; (float)0.01 is the largest float below 0.01, so `<= 0.01f` in float is the same predicate, and "not
+          // both <= 0.01" is "the larger one > 0.01" (the deltas are finite: D >= FLT_EPSILON, sums bounded).
+          const float s2 = __fmaf_rn(dx, dx, dy * dy);
+          const float osc = fmaxf(fabsf(dx + pdx), fabsf(dy + pdy));
+          j++;
+          state = j < prm.max_count ? 0 : 7;
+          if ((__ballot(s2 >= prm.eps2_hi) & __ballot(osc > 0.01f)) == 0ull) {
+            if (lk_converged(dx, dy, prm)) {
+              state = 5;
+            } else if (__ballot(osc <= 0.01f) != 0ull) {
+              nx -= dx * 0.5f;
+              ny -= dy * 0.5f;
+              state = 6;
+            }
+          }
+          pdx = dx;
+          pdy = dy;
         }
-        const float fb1 = bsum[0] * FLT_SCALE, fb2 = bsum[1] * FLT_SCALE;
-        const float dx = (A12 * fb2 - A22 * fb1) * D;
-        const float dy = (A12 * fb1 - A11 * fb2) * D;
-        cx += dx;
-        cy += dy;
-        nx = cx + half;
-        ny = cy + half;
-        if (lk_converged(dx, dy, prm)) {
-          end_kind = 5;
-          break;
-        }
-        // cv compares the float sums with the double 0.01; (float)0.01 is the largest float below
-        // 0.01, so `<= 0.01f` in float is the same predicate
-        if (j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f) {
-          nx -= dx * 0.5f;
-          ny -= dy * 0.5f;
-          end_kind = 6;
-          break;
-        }
-        pdx = dx;
-        pdy = dy;
       }
+      end_kind = state;
+      if (state == 8 && level == 0) status = false;
 #ifdef VSF_LK_STATS
       if ((threadIdx.x & 63) == 0) {
         atomicAdd(&g_lk_stats[level * 16 + 2], (unsigned long long)n_iter);
