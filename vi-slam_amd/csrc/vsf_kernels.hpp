@@ -17,7 +17,7 @@
 #include <type_traits>
 
 #ifndef VSF_LK_WAVES
-#define VSF_LK_WAVES 5  // launch bound of the LK kernels (window <= 21): the compiler settles at 80 registers, no spills, 6 waves per SIMD
+#define VSF_LK_WAVES 7  // launch bound of the LK kernels (window <= 21): 72 registers, 4608 bytes of LDS: seven waves per SIMD (eight run at a lower clock and spill more: 2.77 against 2.61 ms)
 #endif
 #ifndef VSF_SUM_LDS
 #define VSF_SUM_LDS 1  // exact sums through the LDS atomic unit (0: DPP + v_readlane only)

@@ -424,7 +424,6 @@ struct LkSmem {
   int jp_pitch;   // J region in PAIR layout: dwords per row (4 * gj.ndw pairs + 2 of padding)
   int off_j, off_d;
   int off_acc;   // 4 x int64 accumulators of the exact sums
-  int off_mask;  // per lane: NP dwords, 16-bit masks of the window pixels the lane owns (pair-packed)
   int total;
 };
 
@@ -460,9 +459,7 @@ __host__ __device__ inline LkSmem lk_smem_layout(int win, int jmargin) {
   const int sj = s.jp_pitch * 4 * s.gj.rows + 64, sd = s.d_pitch * (win + 1) * 4;
   s.off_d = s.off_j;
   s.off_acc = s.off_j + (((sj > sd ? sj : sd) + 15) & ~15);
-  s.off_mask = s.off_acc + 32;
-  const int np = (lk_seg_template(lk_seglen(win)) + 1) / 2;
-  s.total = s.off_mask + 64 * 4 * np;
+  s.total = s.off_acc + 32;  // 4608 bytes at 21x21: four 1280-byte units, eight waves per SIMD as far as LDS goes
 #ifdef VSF_LDS_PAD  // occupancy experiments
   s.total += VSF_LDS_PAD;
 #endif
@@ -607,20 +604,19 @@ __device__ __forceinline__ void lk_wave_sync() {
 struct LkLaneMap {
   int rowI;                  // byte offset of the lane's row in the I patch
   const unsigned int* rowJ0; // the lane's first pixel in the J pair region (row rr, column xx0)
-  const unsigned int* sMask; // the lane's ownership masks
+  int cnt;                   // window pixels the lane owns (0 for an idle lane)
   int rr, xx0;
 };
 
 template <int SEG>
 __device__ __forceinline__ LkLaneMap lk_lane_map(int lane, const LkParams& prm, uint8_t* smem, const LkSmem& L) {
-  constexpr int NP = (SEG + 1) / 2;
   LkLaneMap m;
   const int r = (lane * prm.nseg_inv) >> 16;  // lane / nseg
   const int x0 = (lane - r * prm.nseg) * prm.seglen;
   const bool owner = (r < prm.win) && (x0 < prm.win);  // lane owns at least one window pixel
   m.rr = owner ? r : 0;                                // idle lanes read a valid (unused) place
   m.xx0 = owner ? x0 : 0;
-  m.sMask = reinterpret_cast<const unsigned int*>(smem + L.off_mask) + lane * NP;
+  m.cnt = owner ? min(prm.seglen, prm.win - x0) : 0;
   m.rowI = __mul24(m.rr, L.gi.pitch);
   m.rowJ0 = reinterpret_cast<unsigned int*>(smem + L.off_j) + __mul24(m.rr, L.jp_pitch) + m.xx0;
   return m;
@@ -662,9 +658,23 @@ __device__ __forceinline__ void lk_template(uint8_t* smem, const LkSmem& L, cons
   unsigned int IwP[NP];
   const unsigned int W0 = ((unsigned int)iw00 & 0xffffu) | ((unsigned int)iw01 << 16);
   const unsigned int W1 = ((unsigned int)iw10 & 0xffffu) | ((unsigned int)iw11 << 16);
+  // ownership masks, 16 bits per window pixel the lane owns (pixels it does not own carry zero gradients): pair k2
+  // holds pixels 2 k2 and 2 k2 + 1, so its mask is the low 32 bits of (1 << 16 * clamp(cnt - 2 k2, 0, 2)) - 1.
+  // (They were a 1 KB table in LDS; without it the kernel's LDS fits eight waves per SIMD.)
   unsigned int pm[NP];
+  if (prm.win == prm.nseg * prm.seglen && prm.seglen == SEG) {
+    // full segments cover the row exactly (21 = 3 x 7): a lane owns all of its pixels or none, and slot SEG of an
+    // odd SEG is zero by construction
+    const unsigned int own = m.cnt > 0 ? 0xffffffffu : 0u;
 #pragma unroll
-  for (int k2 = 0; k2 < NP; k2++) pm[k2] = m.sMask[k2];
+    for (int k2 = 0; k2 < NP; k2++) pm[k2] = own;
+  } else {
+#pragma unroll
+    for (int k2 = 0; k2 < NP; k2++) {
+      const int c = min(max(m.cnt - 2 * k2, 0), 2);
+      pm[k2] = (unsigned int)((1ull << (16 * c)) - 1ull);
+    }
+  }
   if (interior) {
     // Fast path.  The Scharr operator and the bilinear interpolation are both linear and integer,
     // so sum_w(w * Scharr(I)) == Scharr(V) with V = sum_w(w * I) (22 bits) evaluated on the window
@@ -1198,22 +1208,6 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
   return status;
 }
 
-// Fills the per-lane ownership masks in LDS (once per kernel): 16 bits per window pixel the lane owns.
-template <int SEG>
-__device__ __forceinline__ void lk_init_masks(const LkParams& prm, uint8_t* smem, const LkSmem& L) {
-  constexpr int NP = (SEG + 1) / 2;
-  const int lane = threadIdx.x & 63;
-  const int r = lane / prm.nseg;
-  const int x0 = (lane - r * prm.nseg) * prm.seglen;
-  const bool owner = (r < prm.win) && (x0 < prm.win);
-  const int cnt = owner ? min(prm.seglen, prm.win - x0) : 0;
-  unsigned int* m = reinterpret_cast<unsigned int*>(smem + L.off_mask) + lane * NP;
-#pragma unroll
-  for (int k2 = 0; k2 < NP; k2++)
-    m[k2] = (2 * k2 + 1 < cnt) ? 0xffffffffu : ((2 * k2 < cnt) ? 0x0000ffffu : 0u);
-  lk_wave_sync();
-}
-
 // flags bit0 = forward found, bit1 = backward found, bit2 = verified (kept).
 // ref: FeatureTrackerLucasKanade.cpp:36-80 (forward, backward on the forward survivors, then
 // ||back - original||_2 <= threshold in double against the ORIGINAL double position).
@@ -1247,7 +1241,6 @@ __global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_fb_kerne
   const int nf = n[stream];
   if (f0 >= nf) return;
   const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
-  lk_init_masks<SEG>(prm, smem, L);
   const long long so = (long long)stream * cap;
   for (int f = f0; f < nf; f += fgrid) {
     const double2 p0 = xy[so + f];
@@ -1296,7 +1289,6 @@ __global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_points_k
   const int f = blockIdx.x;
   if (f >= n) return;
   const LkSmem L = lk_smem_layout(prm.win, prm.jmargin);
-  lk_init_masks<SEG>(prm, smem, L);
   const float2 p = pts[f];
   float qx, qy;
   const bool st = lk_track_point<SEG>(P, C, 0, p.x, p.y, qx, qy, prm, smem, L);
