@@ -482,7 +482,7 @@ template <int N>
 __device__ __forceinline__ void region_load_regs(unsigned int (&reg)[N], const uint8_t* __restrict__ src, int sp,
                                                  int xa, int y0, const RegionGeom& g, int lane) {
   const int cl = g.ndw <= 8 ? 3 : 4;
-  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  const int xd = lane & ((1 << cl) - 1), yl = (lane >> cl) & ((64 >> cl) - 1), ystep = 64 >> cl;  // (the mask tells the compiler yl's range: `lane` is opaque)
   const unsigned int* s = reinterpret_cast<const unsigned int*>(src + (long long)y0 * sp + xa);
   const unsigned int spw = (unsigned int)sp >> 2;
   // rows and pitches are far below 2^24: v_mad_u32_u24, not the 64-bit multiply-add a plain 32-bit product takes.
@@ -501,7 +501,7 @@ template <int N>
 __device__ __forceinline__ void region_store_regs(uint8_t* dst, const unsigned int (&reg)[N], const RegionGeom& g,
                                                   int lane) {
   const int cl = g.ndw <= 8 ? 3 : 4;
-  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  const int xd = lane & ((1 << cl) - 1), yl = (lane >> cl) & ((64 >> cl) - 1), ystep = 64 >> cl;  // (the mask tells the compiler yl's range: `lane` is opaque)
   unsigned int* d = reinterpret_cast<unsigned int*>(dst);
   const int pw = g.pitch >> 2;
   const int off = yl * pw + xd, step = ystep * pw;
@@ -517,7 +517,7 @@ template <int N>
 __device__ __forceinline__ void region_stage_slow(uint8_t* dst, const uint8_t* __restrict__ src, int sp, int sw,
                                                   int sh, int xa, int y0, const RegionGeom& g, int lane) {
   const int cl = g.ndw <= 8 ? 3 : 4;
-  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  const int xd = lane & ((1 << cl) - 1), yl = (lane >> cl) & ((64 >> cl) - 1), ystep = 64 >> cl;  // (the mask tells the compiler yl's range: `lane` is opaque)
   unsigned int* d = reinterpret_cast<unsigned int*>(dst);
   const int pw = g.pitch >> 2;
   if (xd < g.ndw) {
@@ -546,7 +546,7 @@ template <int N>
 __device__ __forceinline__ void region_store_pairs(unsigned int* dst, const unsigned int (&reg)[N], const RegionGeom& g,
                                                    int pitch_dw, int lane) {
   const int cl = g.ndw <= 8 ? 3 : 4;
-  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  const int xd = lane & ((1 << cl) - 1), yl = (lane >> cl) & ((64 >> cl) - 1), ystep = 64 >> cl;  // (the mask tells the compiler yl's range: `lane` is opaque)
   const int off = yl * pitch_dw + 4 * xd, step = ystep * pitch_dw;
   const bool xin = xd < g.ndw;
 #pragma unroll
@@ -569,7 +569,7 @@ __device__ __forceinline__ void region_stage_slow_pairs(unsigned int* dst, const
                                                         int sw, int sh, int xa, int y0, const RegionGeom& g,
                                                         int pitch_dw, int lane) {
   const int cl = g.ndw <= 8 ? 3 : 4;
-  const int xd = lane & ((1 << cl) - 1), yl = lane >> cl, ystep = 64 >> cl;
+  const int xd = lane & ((1 << cl) - 1), yl = (lane >> cl) & ((64 >> cl) - 1), ystep = 64 >> cl;  // (the mask tells the compiler yl's range: `lane` is opaque)
   if (xd < g.ndw) {
     for (int y = yl; y < g.rows; y += ystep) {
       const uint8_t* sr = src + (long long)reflect101(y0 + y, sh) * sp;
