@@ -15,6 +15,7 @@ python3 - <<PY
 import json
 d=json.load(open("$out/${tag}_bench.json"))
 print("value %.0f  ms/step %.3f  kernel_ms %s" % (d["value"], d["ms_per_step"], {k: round(v,3) for k,v in d["kernel_ms"].items()}))
-print("sclk", d["roofline"]["sclk_mhz_under_load"])
+c = d["roofline"]["sclk_mhz_under_load"]
+print("sclk %.0f MHz   lk %.0f kcycles   score %.0f kcycles   step %.0f kcycles" % (c, d["kernel_ms"]["lk"] * c, d["kernel_ms"]["score"] * c, d["ms_per_step"] * c))
 PY
 exit $rc

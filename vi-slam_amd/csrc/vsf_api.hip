@@ -239,16 +239,16 @@ PyrView make_view(const vsf_ctx* c, const FrameRef& f, const PyrSet& ps) {
   memset(&v, 0, sizeof(v));
   v.nlevels = c->nlevels;
   for (int l = 0; l < c->nlevels; l++) {
-    v.w[l] = c->lw[l];
-    v.h[l] = c->lh[l];
+    v.lv[l].w = c->lw[l];
+    v.lv[l].h = c->lh[l];
     if (l == 0) {
-      v.base[0] = f.ptr;
-      v.sstride[0] = f.sstride;
-      v.pitch[0] = f.pitch;
+      v.lv[0].base = f.ptr;
+      v.lv[0].sstride = f.sstride;
+      v.lv[0].pitch = f.pitch;
     } else {
-      v.base[l] = ps.lv[l];
-      v.sstride[l] = (long long)c->lp[l] * c->lh[l];
-      v.pitch[l] = c->lp[l];
+      v.lv[l].base = ps.lv[l];
+      v.lv[l].sstride = (long long)c->lp[l] * c->lh[l];
+      v.lv[l].pitch = c->lp[l];
     }
   }
   return v;
@@ -1669,11 +1669,11 @@ int vsf_lk_points_noalloc(const vsf_params* p, const uint8_t* d_prev, int32_t pr
     memset(&V[k], 0, sizeof(PyrView));
     V[k].nlevels = nlevels;
     for (int l = 0; l < nlevels; l++) {
-      V[k].w[l] = lw[l];
-      V[k].h[l] = lh[l];
-      V[k].base[l] = l ? lv[k][l] : fr[k].ptr;
-      V[k].sstride[l] = l ? (long long)lp[l] * lh[l] : fr[k].sstride;
-      V[k].pitch[l] = l ? lp[l] : fr[k].pitch;
+      V[k].lv[l].w = lw[l];
+      V[k].lv[l].h = lh[l];
+      V[k].lv[l].base = l ? lv[k][l] : fr[k].ptr;
+      V[k].lv[l].sstride = l ? (long long)lp[l] * lh[l] : fr[k].sstride;
+      V[k].lv[l].pitch = l ? lp[l] : fr[k].pitch;
     }
   }
   const LkParams lk = make_lk_params(p);

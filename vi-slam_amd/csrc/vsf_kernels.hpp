@@ -46,11 +46,17 @@ constexpr int MAXL = 8;      // pyramid levels supported (klt_max_level <= 7)
 constexpr int MAX_WIN = 31;  // LK window side supported
 constexpr int W_BITS = 14;
 
+// One level = one 32-byte record: a kernel that walks the levels fetches a level's description with ONE scalar load
+// (as five arrays indexed by the level it took five loads and five address computations per level and pyramid).
+struct PyrLevel {
+  const uint8_t* base;  // level l of stream 0
+  long long sstride;    // bytes between consecutive streams at level l
+  int pitch, w, h;
+  int pad;
+};
 struct PyrView {
-  const uint8_t* base[MAXL];   // level l of stream 0
-  long long sstride[MAXL];     // bytes between consecutive streams at level l
-  int pitch[MAXL], w[MAXL], h[MAXL];
-  int nlevels;                 // effective maxLevel + 1
+  PyrLevel lv[MAXL];
+  int nlevels;          // effective maxLevel + 1
 };
 
 struct LkParams {

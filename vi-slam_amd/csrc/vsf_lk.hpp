@@ -625,18 +625,18 @@ __device__ __forceinline__ LkLaneMap lk_lane_map(int lane, const LkParams& prm, 
 // This level's I patch into LDS: aligned dwords when interior, assembled byte-wise at the border.
 // ipx, ipy wave-uniform.
 template <int SEG>
-__device__ __forceinline__ void lk_stage_i(const PyrView& A, int level, int stream, int ipx, int ipy, uint8_t* sI,
+__device__ __forceinline__ void lk_stage_i(const PyrLevel& a, int stream, int ipx, int ipy, uint8_t* sI,
                                            const LkSmem& L, int lane) {
   constexpr int NI = (SEG <= 8) ? 3 : 9;  // I-patch staging tasks per lane (win <= 21: 24 rows / 8; <= 31: 34 / 4)
-  const int aw = A.w[level], ah = A.h[level];
+  const int aw = a.w, ah = a.h;
   const int xaI = (ipx - 1) & ~3;
-  const uint8_t* Ab = A.base[level] + (long long)stream * A.sstride[level];
-  if (region_is_fast(Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi)) {
+  const uint8_t* Ab = a.base + (long long)stream * a.sstride;
+  if (region_is_fast(Ab, a.pitch, aw, ah, xaI, ipy - 1, L.gi)) {
     unsigned int ri[NI];
-    region_load_regs<NI>(ri, Ab, A.pitch[level], xaI, ipy - 1, L.gi, lane);
+    region_load_regs<NI>(ri, Ab, a.pitch, xaI, ipy - 1, L.gi, lane);
     region_store_regs<NI>(sI, ri, L.gi, lane);
   } else {
-    region_stage_slow<NI>(sI, Ab, A.pitch[level], aw, ah, xaI, ipy - 1, L.gi, lane);
+    region_stage_slow<NI>(sI, Ab, a.pitch, aw, ah, xaI, ipy - 1, L.gi, lane);
   }
 }
 
@@ -1017,16 +1017,17 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     const float fpx = floorf(px), fpy = floorf(py);
     const int ipx = uniform_f2i(fpx);
     const int ipy = uniform_f2i(fpy);
-    const int aw = A.w[level], ah = A.h[level];
+    const PyrLevel la = A.lv[level], lb = B.lv[level];  // one scalar load each
+    const int aw = la.w, ah = la.h;
     const bool in_range = !(ipx < -win || ipx >= aw || ipy < -win || ipy >= ah);
     const bool cached = (SEG <= 8) && tc.rd_hdr != nullptr;  // wave-uniform
 
-    if (in_range && !cached) lk_stage_i<SEG>(A, level, stream, ipx, ipy, sI, L, lane);
+    if (in_range && !cached) lk_stage_i<SEG>(la, stream, ipx, ipy, sI, L, lane);
     lk_wave_sync();
     if (in_range) VSF_LKSTAT(level * 16 + 0);
 
-    const uint8_t* Bb = B.base[level] + (long long)stream * B.sstride[level];
-    const int bp = B.pitch[level], bw = B.w[level], bh = B.h[level];
+    const uint8_t* Bb = lb.base + (long long)stream * lb.sstride;
+    const int bp = lb.pitch, bw = lb.w, bh = lb.h;
     bool level_ok = in_range;
     if (!in_range && level == 0) status = false;
 
