@@ -210,6 +210,31 @@ __device__ __forceinline__ void sums_to_scalars2(const long long (&t)[2], int (&
       : "scc");
 }
 
+__device__ __forceinline__ void sums_to_scalars3(const long long (&t)[3], int (&lo)[3], int (&hi)[3], int& wide) {
+  int x0, x1;
+  asm volatile(
+      "v_readfirstlane_b32 %0, %9\n\t"
+      "v_readfirstlane_b32 %1, %10\n\t"
+      "v_readfirstlane_b32 %2, %11\n\t"
+      "v_readfirstlane_b32 %3, %12\n\t"
+      "v_readfirstlane_b32 %4, %13\n\t"
+      "v_readfirstlane_b32 %5, %14\n\t"
+      "s_ashr_i32 %7, %0, 31\n\t"
+      "s_ashr_i32 %8, %2, 31\n\t"
+      "s_xor_b32 %7, %7, %1\n\t"
+      "s_xor_b32 %8, %8, %3\n\t"
+      "s_or_b32 %6, %7, %8\n\t"
+      "s_ashr_i32 %7, %4, 31\n\t"
+      "s_xor_b32 %7, %7, %5\n\t"
+      "s_or_b32 %6, %6, %7"
+      : "=&s"(lo[0]), "=&s"(hi[0]), "=&s"(lo[1]), "=&s"(hi[1]), "=&s"(lo[2]), "=&s"(hi[2]), "=&s"(wide), "=&s"(x0),
+        "=&s"(x1)
+      : "v"((int)(unsigned int)(unsigned long long)t[0]), "v"((int)(t[0] >> 32)),
+        "v"((int)(unsigned int)(unsigned long long)t[1]), "v"((int)(t[1] >> 32)),
+        "v"((int)(unsigned int)(unsigned long long)t[2]), "v"((int)(t[2] >> 32))
+      : "scc");
+}
+
 template <int N, int NRAW>
 __device__ __forceinline__ void wave_sums_exact_lds(const int (&p)[N], float (&out)[N], long long* acc, int lane) {
   (void)lane;
@@ -227,13 +252,16 @@ __device__ __forceinline__ void wave_sums_exact_lds(const int (&p)[N], float (&o
       out[1] = exact_i64_to_f32(lo[1], hi[1]);
     }
   } else {
-    int los[N], his[N];
-    to_sgpr4((int)(unsigned int)(unsigned long long)t[0], (int)(t[0] >> 32), (int)(unsigned int)(unsigned long long)t[1],
-             (int)(t[1] >> 32), los[0], his[0], los[1], his[1]);
-    to_sgpr2((int)(unsigned int)(unsigned long long)t[N - 1], (int)(t[N - 1] >> 32), los[N - 1], his[N - 1]);
-    // scalar from here on: the range test and the recombination cost no vector instruction
+    int lo[3], hi[3], wide;
+    sums_to_scalars3(t, lo, hi, wide);
+    if (wide == 0) {
 #pragma unroll
-    for (int i = 0; i < N; i++) out[i] = exact_i64_to_f32(los[i], his[i]);
+      for (int i = 0; i < 3; i++) out[i] = (float)lo[i];
+    } else {
+      asm volatile("");
+#pragma unroll
+      for (int i = 0; i < 3; i++) out[i] = exact_i64_to_f32(lo[i], hi[i]);
+    }
   }
 }
 
@@ -955,7 +983,7 @@ constexpr int LK_TPL_U4 = 160;  // uint4 per (slot, level): IxP [64], IyP [64], 
 
 struct LkCacheBuf {
   uint4* tpl;   // [streams][cap][levels][LK_TPL_U4]
-  float4* hdr;  // [streams][cap][levels]  {flags (bit0 in range) as int bits, A11, A12, A22}
+  float4* hdr;  // [streams][cap][levels]  {1 / det (0: level rejected or out of range), A11, A12, A22}
   float4* tag;  // [streams][cap]          {qx, qy, epoch as int bits, 0}
 };
 struct LkCache {
@@ -1037,7 +1065,9 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     if (level_ok && cached) {
       VSF_LKSTAT(level * 16 + 9);
       if constexpr (SEG <= 8) {
-        // the entry the previous step's backward pass left for this image and position
+        // the entry the previous step's backward pass left for this image and position: gradients, constants, the
+        // normal matrix and 1 / det (0 = the level was rejected: cv's min-eigenvalue / determinant test), so neither the
+        // test nor the division is repeated here
         const float4 h = tc.rd_hdr[level];
         const uint4* t = tc.rd_tpl + level * LK_TPL_U4;
         const uint4 gx = t[lane], gy = t[64 + lane];
@@ -1049,7 +1079,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
         A11 = h.y;
         A12 = h.z;
         A22 = h.w;
-        if (lk_reject_level(A11, A12, A22, D, prm)) {
+        D = h.x;
+        if (__ballot(D == 0.f) != 0ull) {
           if (level == 0) status = false;
           level_ok = false;
         }
@@ -1072,18 +1103,21 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
       A11 = Asum[0] * FLT_SCALE;
       A12 = Asum[1] * FLT_SCALE;
       A22 = Asum[2] * FLT_SCALE;
+      if (lk_reject_level(A11, A12, A22, D, prm)) {
+        if (level == 0) status = false;
+        level_ok = false;
+        D = 0.f;
+      } else {
+        D = 1.f / D;
+      }
       if constexpr (SEG <= 8) {
         if (tc.wr_hdr != nullptr) {  // leave the template for the next step's forward pass (fire and forget)
           uint4* t = tc.wr_tpl + level * LK_TPL_U4;
           t[lane] = make_uint4(IxP[0], IxP[1], IxP[2], IxP[3]);
           t[64 + lane] = make_uint4(IyP[0], IyP[1], IyP[2], IyP[3]);
           reinterpret_cast<uint2*>(t + 128)[lane] = make_uint2((unsigned int)ncI1, (unsigned int)ncI2);
-          if (lane == 0) tc.wr_hdr[level] = make_float4(__int_as_float(1), A11, A12, A22);
+          if (lane == 0) tc.wr_hdr[level] = make_float4(D, A11, A12, A22);
         }
-      }
-      if (lk_reject_level(A11, A12, A22, D, prm)) {
-        if (level == 0) status = false;
-        level_ok = false;
       }
     }
     if constexpr (SEG <= 8) {
@@ -1094,7 +1128,6 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     if (level_ok) {
       VSF_LKSTAT(level * 16 + 1);
       int n_iter = 0, end_kind = 7;
-      D = 1.f / D;
       float cx = nx - half, cy = ny - half;  // nextPt - halfWin
       // cv tests the oscillation rule from the second iteration on (j > 0): a first "previous delta" this large
       // fails it by itself
