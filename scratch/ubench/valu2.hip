@@ -1,5 +1,6 @@
 // Issue cost of single vector instructions on gfx950, in SHADER CYCLES (s_memtime deltas inside the kernel, not
-// wall time at an assumed clock): W waves per SIMD each run a loop of 32 independent copies of one instruction.
+// wall time at an assumed clock): W waves per SIMD each run a loop of 32 copies of one instruction whose destinations rotate over four registers (two for the
+// float forms), so that consecutive copies do not wait on each other's write.
 //   hipcc -O3 --offload-arch=gfx950 scratch/ubench/valu2.hip -o scratch/ubench/valu2 && scratch/ubench/valu2
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -7,7 +8,7 @@
 #include <algorithm>
 
 #define REP8(X) X X X X X X X X
-#define REP32(X) REP8(X) REP8(X) REP8(X) REP8(X)
+#define REP32(X) REP8(X)  // each X holds four copies with rotating destination registers
 
 #define KERNEL(NAME, ASM)                                                                           \
   __global__ __launch_bounds__(256) void NAME(unsigned long long* out, int iters, int a, float f) { \
@@ -31,43 +32,43 @@
   }
 
 // operands: %0..%3 int dst, %4 %5 float dst, %6 double dst, %7 sgpr dst; %8..%11 int src, %12 %13 float src, %14 %15 double src
-KERNEL(k_add, "v_add_u32 %0, %8, %9\n")
-KERNEL(k_dot2c, "v_dot2c_i32_i16 %0, %8, %9\n")
-KERNEL(k_dot2_3op, "v_dot2_i32_i16 %0, %8, %9, %10\n")
-KERNEL(k_udot2, "v_dot2_u32_u16 %0, %8, %9, %10\n")
-KERNEL(k_bfe, "v_bfe_u32 %0, %8, 9, 16\n")
-KERNEL(k_ashr, "v_ashrrev_i32 %0, 9, %8\n")
-KERNEL(k_sdwa, "v_ashrrev_i32_sdwa %0, 9, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n")
-KERNEL(k_perm, "v_perm_b32 %0, %8, %9, %10\n")
-KERNEL(k_dpp, "v_add_u32_dpp %0, %8, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
-KERNEL(k_rfl, "v_readfirstlane_b32 %7, %8\n")
-KERNEL(k_mulf, "v_mul_f32 %4, %12, %13\n")
-KERNEL(k_fma, "v_fma_f32 %4, %12, %13, %12\n")
-KERNEL(k_pkmul, "v_pk_mul_f32 %6, %14, %15\n")
-KERNEL(k_pkadd, "v_pk_add_f32 %6, %14, %15\n")
-KERNEL(k_cvt_f32_i32, "v_cvt_f32_i32 %4, %8\n")
-KERNEL(k_cvt_i32_f32, "v_cvt_i32_f32 %0, %12\n")
-KERNEL(k_floor, "v_floor_f32 %4, %12\n")
-KERNEL(k_cmp, "v_cmp_lt_f32 vcc, %12, %13\n")
-KERNEL(k_cndmask, "v_cndmask_b32 %0, %8, %9, vcc\n")
-KERNEL(k_mad24, "v_mad_i32_i24 %0, %8, %9, %10\n")
-KERNEL(k_mul24, "v_mul_i32_i24 %0, %8, %9\n")
-KERNEL(k_and, "v_and_b32 %0, %8, %9\n")
-KERNEL(k_and_or, "v_and_or_b32 %0, %8, %9, %10\n")
-KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %8, 3, %9\n")
-KERNEL(k_alignbyte, "v_alignbyte_b32 %0, %8, %9, %10\n")
-KERNEL(k_mov, "v_mov_b32 %0, %8\n")
-KERNEL(k_cvt_f64_f32, "v_cvt_f64_f32 %6, %12\n")
-KERNEL(k_add_f64, "v_add_f64 %6, %14, %15\n")
-KERNEL(k_cvt_f32_f64, "v_cvt_f32_f64 %4, %14\n")
-KERNEL(k_sqrt, "v_sqrt_f32 %4, %12\n")
-KERNEL(k_snop, "s_nop 0\n")
-KERNEL(k_salu, "s_add_u32 %7, %7, 1\n")
-KERNEL(k_pk_mad_u16, "v_pk_mad_u16 %0, %8, %9, %10\n")
-KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %8, %9\n")
-KERNEL(k_mad_u32_u24, "v_mad_u32_u24 %0, %8, %9, %10\n")
-KERNEL(k_sub_f32, "v_sub_f32 %4, %12, %13\n")
-KERNEL(k_max_f32, "v_max_f32 %4, %12, %13\n")
+KERNEL(k_add, "v_add_u32 %0, %8, %9\nv_add_u32 %1, %8, %9\nv_add_u32 %2, %8, %9\nv_add_u32 %3, %8, %9\n")
+KERNEL(k_dot2c, "v_dot2c_i32_i16 %0, %8, %9\nv_dot2c_i32_i16 %1, %8, %9\nv_dot2c_i32_i16 %2, %8, %9\nv_dot2c_i32_i16 %3, %8, %9\n")
+KERNEL(k_dot2_3op, "v_dot2_i32_i16 %0, %8, %9, %10\nv_dot2_i32_i16 %1, %8, %9, %10\nv_dot2_i32_i16 %2, %8, %9, %10\nv_dot2_i32_i16 %3, %8, %9, %10\n")
+KERNEL(k_udot2, "v_dot2_u32_u16 %0, %8, %9, %10\nv_dot2_u32_u16 %1, %8, %9, %10\nv_dot2_u32_u16 %2, %8, %9, %10\nv_dot2_u32_u16 %3, %8, %9, %10\n")
+KERNEL(k_bfe, "v_bfe_u32 %0, %8, 9, 16\nv_bfe_u32 %1, %8, 9, 16\nv_bfe_u32 %2, %8, 9, 16\nv_bfe_u32 %3, %8, 9, 16\n")
+KERNEL(k_ashr, "v_ashrrev_i32 %0, 9, %8\nv_ashrrev_i32 %1, 9, %8\nv_ashrrev_i32 %2, 9, %8\nv_ashrrev_i32 %3, 9, %8\n")
+KERNEL(k_sdwa, "v_ashrrev_i32_sdwa %0, 9, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\nv_ashrrev_i32_sdwa %1, 9, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\nv_ashrrev_i32_sdwa %2, 9, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\nv_ashrrev_i32_sdwa %3, 9, %8 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:DWORD\n")
+KERNEL(k_perm, "v_perm_b32 %0, %8, %9, %10\nv_perm_b32 %1, %8, %9, %10\nv_perm_b32 %2, %8, %9, %10\nv_perm_b32 %3, %8, %9, %10\n")
+KERNEL(k_dpp, "v_add_u32_dpp %0, %8, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\nv_add_u32_dpp %1, %8, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\nv_add_u32_dpp %2, %8, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\nv_add_u32_dpp %3, %8, %9 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n")
+KERNEL(k_rfl, "v_readfirstlane_b32 %7, %8\nv_readfirstlane_b32 %7, %8\nv_readfirstlane_b32 %7, %8\nv_readfirstlane_b32 %7, %8\n")
+KERNEL(k_mulf, "v_mul_f32 %4, %12, %13\nv_mul_f32 %5, %12, %13\nv_mul_f32 %4, %12, %13\nv_mul_f32 %5, %12, %13\n")
+KERNEL(k_fma, "v_fma_f32 %4, %12, %13, %12\nv_fma_f32 %5, %12, %13, %12\nv_fma_f32 %4, %12, %13, %12\nv_fma_f32 %5, %12, %13, %12\n")
+KERNEL(k_pkmul, "v_pk_mul_f32 %6, %14, %15\nv_pk_mul_f32 %6, %14, %15\nv_pk_mul_f32 %6, %14, %15\nv_pk_mul_f32 %6, %14, %15\n")
+KERNEL(k_pkadd, "v_pk_add_f32 %6, %14, %15\nv_pk_add_f32 %6, %14, %15\nv_pk_add_f32 %6, %14, %15\nv_pk_add_f32 %6, %14, %15\n")
+KERNEL(k_cvt_f32_i32, "v_cvt_f32_i32 %4, %8\nv_cvt_f32_i32 %5, %8\nv_cvt_f32_i32 %4, %8\nv_cvt_f32_i32 %5, %8\n")
+KERNEL(k_cvt_i32_f32, "v_cvt_i32_f32 %0, %12\nv_cvt_i32_f32 %1, %12\nv_cvt_i32_f32 %2, %12\nv_cvt_i32_f32 %3, %12\n")
+KERNEL(k_floor, "v_floor_f32 %4, %12\nv_floor_f32 %5, %12\nv_floor_f32 %4, %12\nv_floor_f32 %5, %12\n")
+KERNEL(k_cmp, "v_cmp_lt_f32 vcc, %12, %13\nv_cmp_lt_f32 vcc, %12, %13\nv_cmp_lt_f32 vcc, %12, %13\nv_cmp_lt_f32 vcc, %12, %13\n")
+KERNEL(k_cndmask, "v_cndmask_b32 %0, %8, %9, vcc\nv_cndmask_b32 %1, %8, %9, vcc\nv_cndmask_b32 %2, %8, %9, vcc\nv_cndmask_b32 %3, %8, %9, vcc\n")
+KERNEL(k_mad24, "v_mad_i32_i24 %0, %8, %9, %10\nv_mad_i32_i24 %1, %8, %9, %10\nv_mad_i32_i24 %2, %8, %9, %10\nv_mad_i32_i24 %3, %8, %9, %10\n")
+KERNEL(k_mul24, "v_mul_i32_i24 %0, %8, %9\nv_mul_i32_i24 %1, %8, %9\nv_mul_i32_i24 %2, %8, %9\nv_mul_i32_i24 %3, %8, %9\n")
+KERNEL(k_and, "v_and_b32 %0, %8, %9\nv_and_b32 %1, %8, %9\nv_and_b32 %2, %8, %9\nv_and_b32 %3, %8, %9\n")
+KERNEL(k_and_or, "v_and_or_b32 %0, %8, %9, %10\nv_and_or_b32 %1, %8, %9, %10\nv_and_or_b32 %2, %8, %9, %10\nv_and_or_b32 %3, %8, %9, %10\n")
+KERNEL(k_lshl_add, "v_lshl_add_u32 %0, %8, 3, %9\nv_lshl_add_u32 %1, %8, 3, %9\nv_lshl_add_u32 %2, %8, 3, %9\nv_lshl_add_u32 %3, %8, 3, %9\n")
+KERNEL(k_alignbyte, "v_alignbyte_b32 %0, %8, %9, %10\nv_alignbyte_b32 %1, %8, %9, %10\nv_alignbyte_b32 %2, %8, %9, %10\nv_alignbyte_b32 %3, %8, %9, %10\n")
+KERNEL(k_mov, "v_mov_b32 %0, %8\nv_mov_b32 %1, %8\nv_mov_b32 %2, %8\nv_mov_b32 %3, %8\n")
+KERNEL(k_cvt_f64_f32, "v_cvt_f64_f32 %6, %12\nv_cvt_f64_f32 %6, %12\nv_cvt_f64_f32 %6, %12\nv_cvt_f64_f32 %6, %12\n")
+KERNEL(k_add_f64, "v_add_f64 %6, %14, %15\nv_add_f64 %6, %14, %15\nv_add_f64 %6, %14, %15\nv_add_f64 %6, %14, %15\n")
+KERNEL(k_cvt_f32_f64, "v_cvt_f32_f64 %4, %14\nv_cvt_f32_f64 %5, %14\nv_cvt_f32_f64 %4, %14\nv_cvt_f32_f64 %5, %14\n")
+KERNEL(k_sqrt, "v_sqrt_f32 %4, %12\nv_sqrt_f32 %5, %12\nv_sqrt_f32 %4, %12\nv_sqrt_f32 %5, %12\n")
+KERNEL(k_snop, "s_nop 0\ns_nop 0\ns_nop 0\ns_nop 0\n")
+KERNEL(k_salu, "s_add_u32 %7, %7, 1\ns_add_u32 %7, %7, 1\ns_add_u32 %7, %7, 1\ns_add_u32 %7, %7, 1\n")
+KERNEL(k_pk_mad_u16, "v_pk_mad_u16 %0, %8, %9, %10\nv_pk_mad_u16 %1, %8, %9, %10\nv_pk_mad_u16 %2, %8, %9, %10\nv_pk_mad_u16 %3, %8, %9, %10\n")
+KERNEL(k_pk_add_u16, "v_pk_add_u16 %0, %8, %9\nv_pk_add_u16 %1, %8, %9\nv_pk_add_u16 %2, %8, %9\nv_pk_add_u16 %3, %8, %9\n")
+KERNEL(k_mad_u32_u24, "v_mad_u32_u24 %0, %8, %9, %10\nv_mad_u32_u24 %1, %8, %9, %10\nv_mad_u32_u24 %2, %8, %9, %10\nv_mad_u32_u24 %3, %8, %9, %10\n")
+KERNEL(k_sub_f32, "v_sub_f32 %4, %12, %13\nv_sub_f32 %5, %12, %13\nv_sub_f32 %4, %12, %13\nv_sub_f32 %5, %12, %13\n")
+KERNEL(k_max_f32, "v_max_f32 %4, %12, %13\nv_max_f32 %5, %12, %13\nv_max_f32 %4, %12, %13\nv_max_f32 %5, %12, %13\n")
 
 typedef void (*kfn)(unsigned long long*, int, int, float);
 struct Entry { const char* name; kfn fn; };
