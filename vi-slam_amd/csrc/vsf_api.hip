@@ -250,6 +250,7 @@ PyrView make_view(const vsf_ctx* c, const FrameRef& f, const PyrSet& ps) {
       v.lv[l].sstride = (long long)c->lp[l] * c->lh[l];
       v.lv[l].pitch = c->lp[l];
     }
+    v.lv[l].aligned = ((uintptr_t)v.lv[l].base % 4 == 0) && v.lv[l].sstride % 4 == 0 && v.lv[l].pitch % 4 == 0;
   }
   return v;
 }
@@ -1674,6 +1675,7 @@ int vsf_lk_points_noalloc(const vsf_params* p, const uint8_t* d_prev, int32_t pr
       V[k].lv[l].base = l ? lv[k][l] : fr[k].ptr;
       V[k].lv[l].sstride = l ? (long long)lp[l] * lh[l] : fr[k].sstride;
       V[k].lv[l].pitch = l ? lp[l] : fr[k].pitch;
+      V[k].lv[l].aligned = ((uintptr_t)V[k].lv[l].base % 4 == 0) && V[k].lv[l].sstride % 4 == 0 && V[k].lv[l].pitch % 4 == 0;
     }
   }
   const LkParams lk = make_lk_params(p);

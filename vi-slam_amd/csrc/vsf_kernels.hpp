@@ -52,7 +52,7 @@ struct PyrLevel {
   const uint8_t* base;  // level l of stream 0
   long long sstride;    // bytes between consecutive streams at level l
   int pitch, w, h;
-  int pad;
+  int aligned;          // base, stream stride and pitch are multiples of 4: regions can be fetched as dwords
 };
 struct PyrView {
   PyrLevel lv[MAXL];

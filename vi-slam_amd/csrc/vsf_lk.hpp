@@ -496,10 +496,11 @@ __host__ __device__ inline LkSmem lk_smem_layout(int win, int jmargin) {
 
 // A region [xa, xa + 4*ndw) x [y0, y0 + rows) can be fetched as aligned dwords when it lies inside
 // the level and rows are dword aligned; otherwise it is assembled byte by byte with REFLECT_101.
-__device__ __forceinline__ bool region_is_fast(const uint8_t* src, int sp, int sw, int sh, int xa, int y0,
-                                               const RegionGeom& g) {
-  return xa >= 0 && y0 >= 0 && xa + 4 * g.ndw <= sw && y0 + g.rows <= sh && (sp & 3) == 0 &&
-         ((reinterpret_cast<uintptr_t>(src) & 3) == 0);
+// 0 <= xa && xa + 4 ndw <= sw  <=>  (unsigned)xa <= sw - 4 ndw (a level narrower than the region makes the right side
+// negative = huge, so it is tested too); the alignment part is a property of the level (PyrLevel::aligned).
+__device__ __forceinline__ bool region_is_fast(int aligned, int sw, int sh, int xa, int y0, const RegionGeom& g) {
+  const int mx = sw - 4 * g.ndw, my = sh - g.rows;
+  return aligned && (mx | my) >= 0 && (unsigned int)xa <= (unsigned int)mx && (unsigned int)y0 <= (unsigned int)my;
 }
 
 // Staging map (no division): lane -> dword column xd = lane % C and row yl = lane / C, with C = 8 when
@@ -659,7 +660,7 @@ __device__ __forceinline__ void lk_stage_i(const PyrLevel& a, int stream, int ip
   const int aw = a.w, ah = a.h;
   const int xaI = (ipx - 1) & ~3;
   const uint8_t* Ab = a.base + (long long)stream * a.sstride;
-  if (region_is_fast(Ab, a.pitch, aw, ah, xaI, ipy - 1, L.gi)) {
+  if (region_is_fast(a.aligned, aw, ah, xaI, ipy - 1, L.gi)) {
     unsigned int ri[NI];
     region_load_regs<NI>(ri, Ab, a.pitch, xaI, ipy - 1, L.gi, lane);
     region_store_regs<NI>(sI, ri, L.gi, lane);
@@ -885,10 +886,10 @@ __device__ __forceinline__ bool lk_reject_level(float A11, float A12, float A22,
 
 // The J region [jx0, jx0 + 4 ndw) x [jy0, jy0 + rows) of level image Bb into LDS, in pair layout.
 template <int SEG>
-__device__ __forceinline__ void lk_stage_j(const uint8_t* __restrict__ Bb, int bp, int bw, int bh, int jx0, int jy0,
-                                           unsigned int* sJ, const LkSmem& L, int lane) {
+__device__ __forceinline__ void lk_stage_j(const uint8_t* __restrict__ Bb, int bp, int bw, int bh, int aligned, int jx0,
+                                           int jy0, unsigned int* sJ, const LkSmem& L, int lane) {
   constexpr int NJ = (SEG <= 8) ? 4 : 10;  // J-region staging tasks per lane (jmargin 3: 28 rows / 8; 38 / 4)
-  if (region_is_fast(Bb, bp, bw, bh, jx0, jy0, L.gj)) {
+  if (region_is_fast(aligned, bw, bh, jx0, jy0, L.gj)) {
     unsigned int rj[NJ];
     region_load_regs<NJ>(rj, Bb, bp, jx0, jy0, L.gj, lane);
     region_store_pairs<NJ>(sJ, rj, L.gj, L.jp_pitch, lane);
@@ -1047,7 +1048,8 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
     const int ipy = uniform_f2i(fpy);
     const PyrLevel la = A.lv[level], lb = B.lv[level];  // one scalar load each
     const int aw = la.w, ah = la.h;
-    const bool in_range = !(ipx < -win || ipx >= aw || ipy < -win || ipy >= ah);
+    // cv: ip < -win || ip >= size is out of range  <=>  (unsigned)(ip + win) >= size + win
+    const bool in_range = (unsigned int)(ipx + win) < (unsigned int)(aw + win) && (unsigned int)(ipy + win) < (unsigned int)(ah + win);
     const bool cached = (SEG <= 8) && tc.rd_hdr != nullptr;  // wave-uniform
 
     if (in_range && !cached) lk_stage_i<SEG>(la, stream, ipx, ipy, sI, L, lane);
@@ -1159,7 +1161,7 @@ __device__ bool lk_track_point(const PyrView& A, const PyrView& B, int stream, f
             lk_wave_sync();  // previous iteration's reads are done
             jx0 = (inx - prm.jmargin) & ~3;
             jy0 = iny - prm.jmargin;
-            lk_stage_j<SEG>(Bb, bp, bw, bh, jx0, jy0, sJ, L, lane);
+            lk_stage_j<SEG>(Bb, bp, bw, bh, lb.aligned, jx0, jy0, sJ, L, lane);
             VSF_LKSTAT(level * 16 + 3);
             lk_wave_sync();
             // window positions the region serves: jx0 .. jx0 + 4 ndw - win - 1, cut to the level's range -win .. bw - 1
