@@ -65,8 +65,8 @@ typedef struct vsf_params {
    * VSF_DETECTOR_BUCKETING = FeatureDetectorShiTomasiBucketing (fields above),
    * VSF_DETECTOR_ANMS      = FeatureDetectorANMS (FeatureDetectorANMS.cpp:13-212): max_features and
    * min_distance above are its Parameter::max_feature_number_ / min_feature_distance_ (:17-18; the disc
-   * radius is int(min_distance) <= 31); the fields below are the rest of its Parameter (:23-34).
-   * detection_min_feature_distance_ is fixed at the reference's 1.0 and Harris is off (:24,27). */
+   * radius is int(min_distance) <= 31); the fields below are the rest of its Parameter (:23-34), continued
+   * by anms_detection_min_distance / anms_use_harris / anms_harris_k at the end of the struct (:24, :27-28). */
   int32_t detector_kind;
   int32_t anms_detection_features; /* detection_feature_number_; 0 = 2 * max_features (:23); <= 8192 */
   double anms_quality_level;       /* detection_quality_level_ 0.001 (:25) */
@@ -88,6 +88,14 @@ typedef struct vsf_params {
    * (the host-pointer API's staging, the frame-pair buffers) does not fit, the cache is given back first.
    * vsf_get_info reports what the context holds. */
   int64_t lk_cache_max_bytes;
+  /* The rest of FeatureDetectorANMS::Parameter, as passed to cv::GFTTDetector::create (FeatureDetectorANMS.cpp:41-47).
+   * anms_detection_min_distance: detection_min_feature_distance_ 1.0 (:24), cv's minDistance; <= 1 (0 included)
+   * never rejects a corner, above 1 the sorted corners are accepted greedily (<= 31).
+   * anms_use_harris / anms_harris_k: detection_use_harris_corner_ false (:27) / detection_k_ 0.04 (:28): the
+   * response map is cv::cornerHarris instead of cv::cornerMinEigenVal. */
+  double anms_detection_min_distance;
+  int32_t anms_use_harris;
+  double anms_harris_k;
 } vsf_params;
 
 #define VSF_TRACKER_LK 0

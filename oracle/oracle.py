@@ -129,8 +129,18 @@ def corner_min_eigen_val(img, roi=None, block_size=3):
     return out
 
 
+def corner_harris(img, roi=None, block_size=3, k=0.04):
+    img = _img(img)
+    h, w = img.shape
+    rx, ry, rw, rh = [int(v) for v in (roi if roi is not None else (0, 0, w, h))]
+    out = np.empty((rh, rw), np.float32)
+    lib().orc_corner_harris(img.ctypes.data_as(C.c_void_p), w, h, w, rx, ry, rw, rh, block_size, C.c_double(k),
+                            out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def good_features_to_track(img, max_corners, quality, min_dist, roi=None, mask=None,
-                           block_size=3):
+                           block_size=3, use_harris=False, k=0.04):
     img = _img(img)
     h, w = img.shape
     rx, ry, rw, rh = [int(v) for v in (roi if roi is not None else (0, 0, w, h))]
@@ -141,10 +151,10 @@ def good_features_to_track(img, max_corners, quality, min_dist, roi=None, mask=N
         mask = _img(mask)
         mstride = mask.shape[1]
         mptr = C.c_void_p(mask.ctypes.data + ry * mstride + rx)
-    n = lib().orc_good_features_to_track(img.ctypes.data_as(C.c_void_p), w, h, w, rx, ry, rw, rh,
-                                         max_corners, C.c_double(quality), C.c_double(min_dist),
-                                         mptr, mstride, block_size,
-                                         out.ctypes.data_as(C.c_void_p), cap)
+    n = lib().orc_good_features_to_track_ex(img.ctypes.data_as(C.c_void_p), w, h, w, rx, ry, rw, rh,
+                                            max_corners, C.c_double(quality), C.c_double(min_dist),
+                                            mptr, mstride, block_size, 1 if use_harris else 0, C.c_double(k),
+                                            out.ctypes.data_as(C.c_void_p), cap)
     return out[:n].copy()
 
 
@@ -224,7 +234,8 @@ class _AnmsDetector(C.Structure):
                 ("detection_min_feature_distance", C.c_double),
                 ("detection_quality_level", C.c_double), ("detection_block_size", C.c_int32),
                 ("detection_ignore_edge", C.c_int32), ("non_max_suppression_tolerance", C.c_double),
-                ("max_feature_index", C.c_uint64)]
+                ("max_feature_index", C.c_uint64), ("detection_use_harris_corner", C.c_int32),
+                ("detection_k", C.c_double)]
 
 
 def circle_filled(img, cx, cy, radius, color=0):

@@ -359,8 +359,8 @@ int orc_calc_optical_flow_pyr_lk(const uint8_t* prev, int prev_stride, const uin
  * to bottom -- and rounded to float32 once.  (SURVEY A.1 step 3 words this with float sums; the
  * double form is what OpenCV does and makes the result independent of its running-sum order.)
  * The box filter reflects (REFLECT_101) at the borders of the ROI's own covariance image. */
-void orc_corner_min_eigen_val(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
-                              int rw, int rh, int block_size, float* eig) {
+static void corner_response(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry, int rw, int rh,
+                            int block_size, int use_harris, double harris_k, float* eig) {
   const double scale_d = 1.0 / ((double)(1 << 2) * block_size * 255.0);
   const float k_side = (float)(1.0 * scale_d), k_mid = (float)(2.0 * scale_d);
   float* cov = (float*)malloc(sizeof(float) * 3 * (size_t)rw * rh);
@@ -419,11 +419,39 @@ void orc_corner_min_eigen_val(const uint8_t* img, int img_w, int img_h, int stri
           s[2] += r[2];
         }
       }
-      const float a = (float)s[0] * 0.5f, b = (float)s[1], c = (float)s[2] * 0.5f;
-      eig[(size_t)y * rw + x] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+      if (!use_harris) {
+        const float a = (float)s[0] * 0.5f, b = (float)s[1], c = (float)s[2] * 0.5f;
+        eig[(size_t)y * rw + x] = (a + c) - sqrtf((a - c) * (a - c) + b * b);
+      } else {
+        /* cv::cornerHarris -> calcHarris (imgproc/corner.cpp, recalled): the universal-intrinsics loop takes
+         * four pixels at a time in float32 with (float)k -- ac_bb = a*c - b*b; t = a + c; dst = ac_bb - k*t*t,
+         * products left to right -- and the scalar tail (the last width % 4 pixels of a row) evaluates
+         * (float)(a*c - b*b - k*(a + c)*(a + c)) with k a double: a*c - b*b in float, the k term in double. */
+        const float a = (float)s[0], b = (float)s[1], c = (float)s[2];
+        float r;
+        if (x < (rw & ~3)) {
+          const float kf = (float)harris_k;
+          const float ac_bb = a * c - b * b;
+          const float t = a + c;
+          r = ac_bb - kf * t * t;
+        } else {
+          r = (float)((double)(a * c - b * b) - harris_k * (double)(a + c) * (double)(a + c));
+        }
+        eig[(size_t)y * rw + x] = r;
+      }
     }
   }
   free(cov);
+}
+
+void orc_corner_min_eigen_val(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
+                              int rw, int rh, int block_size, float* eig) {
+  corner_response(img, img_w, img_h, stride, rx, ry, rw, rh, block_size, 0, 0.0, eig);
+}
+
+void orc_corner_harris(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry, int rw, int rh,
+                       int block_size, double k, float* dst) {
+  corner_response(img, img_w, img_h, stride, rx, ry, rw, rh, block_size, 1, k, dst);
 }
 
 /* cv: goodFeaturesToTrack -- SURVEY A.1 steps 5-9.  ROI of a parent image; mask (if any) is the
@@ -447,9 +475,17 @@ int orc_good_features_to_track(const uint8_t* img, int img_w, int img_h, int str
                                int rw, int rh, int max_corners, double quality, double min_dist,
                                const uint8_t* mask, int mask_stride, int block_size, float* out_xy,
                                int cap) {
+  return orc_good_features_to_track_ex(img, img_w, img_h, stride, rx, ry, rw, rh, max_corners, quality, min_dist,
+                                       mask, mask_stride, block_size, 0, 0.04, out_xy, cap);
+}
+
+int orc_good_features_to_track_ex(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
+                                  int rw, int rh, int max_corners, double quality, double min_dist,
+                                  const uint8_t* mask, int mask_stride, int block_size, int use_harris,
+                                  double harris_k, float* out_xy, int cap) {
   if (rw <= 0 || rh <= 0) return 0;
   float* eig = (float*)malloc(sizeof(float) * (size_t)rw * rh);
-  orc_corner_min_eigen_val(img, img_w, img_h, stride, rx, ry, rw, rh, block_size, eig);
+  corner_response(img, img_w, img_h, stride, rx, ry, rw, rh, block_size, use_harris, harris_k, eig);
 
   /* cv: minMaxLoc(eig, 0, &maxVal, 0, 0, mask) */
   double maxVal = 0;
@@ -952,6 +988,8 @@ void orc_anms_detector_init(orc_anms_detector* d, int32_t max_features, double m
   d->detection_ignore_edge = 20;
   d->non_max_suppression_tolerance = 0.1;
   d->max_feature_index = 0;
+  d->detection_use_harris_corner = 0;
+  d->detection_k = 0.04;
 }
 
 /* ref: FeatureDetectorANMS.cpp:107-132 */
@@ -992,9 +1030,10 @@ int orc_anms_detector_update(orc_anms_detector* d, const uint8_t* img, int w, in
    * KeyPoint(pt, blockSize): response stays 0 (Q9) */
   const int kcap = d->detection_feature_number > 0 ? d->detection_feature_number : w * h;
   float* kp = (float*)malloc(sizeof(float) * 2 * (size_t)kcap);
-  const int ndet = orc_good_features_to_track(img, w, h, stride, 0, 0, w, h, d->detection_feature_number,
-                                              d->detection_quality_level, d->detection_min_feature_distance,
-                                              flag, w, d->detection_block_size, kp, kcap);
+  const int ndet = orc_good_features_to_track_ex(img, w, h, stride, 0, 0, w, h, d->detection_feature_number,
+                                                 d->detection_quality_level, d->detection_min_feature_distance,
+                                                 flag, w, d->detection_block_size, d->detection_use_harris_corner,
+                                                 d->detection_k, kp, kcap);
   int need = d->max_feature_number - n0; /* :174-175 */
   if (need < 0) need = 0;
   int* sel = (int*)malloc(sizeof(int) * (size_t)(ndet > 0 ? ndet : 1));

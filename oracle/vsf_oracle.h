@@ -66,6 +66,16 @@ int orc_calc_optical_flow_pyr_lk(const uint8_t* prev, int prev_stride, const uin
 void orc_corner_min_eigen_val(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
                               int rw, int rh, int block_size, float* eig);
 
+/* cv::cornerHarris on the ROI (blockSize, ksize 3, k): same covariance sums as the min-eigenvalue map, response
+ * a*c - b*b - k*(a + c)^2 as OpenCV 3.4's calcHarris forms it (float32 in groups of four pixels, the row's last
+ * width % 4 pixels with k in double).  Recalled; PARITY UNPINNED like the rest of the OpenCV arithmetic. */
+void orc_corner_harris(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry, int rw, int rh,
+                       int block_size, double k, float* dst);
+/* goodFeaturesToTrack with useHarrisDetector / k (what cv::GFTTDetector passes on, FeatureDetectorANMS.cpp:41-47) */
+int orc_good_features_to_track_ex(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
+                                  int rw, int rh, int max_corners, double quality, double min_dist,
+                                  const uint8_t* mask, int mask_stride, int block_size, int use_harris,
+                                  double harris_k, float* out_xy, int cap);
 int orc_good_features_to_track(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry,
                                int rw, int rh, int max_corners, double quality, double min_dist,
                                const uint8_t* mask, int mask_stride, int block_size, float* out_xy,
@@ -145,6 +155,8 @@ typedef struct {
   int32_t detection_ignore_edge;          /* 20                                        :29 */
   double non_max_suppression_tolerance;   /* 0.1                                       :34 */
   uint64_t max_feature_index;             /* member, starts at 0                       :39 */
+  int32_t detection_use_harris_corner;    /* false                                     :27 */
+  double detection_k;                     /* 0.04                                      :28 */
 } orc_anms_detector;
 
 void orc_anms_detector_init(orc_anms_detector* d, int32_t max_features, double min_distance);

@@ -111,6 +111,63 @@ def test_min_eig_invariants_and_numpy_crosscheck(oracle):
     assert np.allclose(got, lam, rtol=2e-3, atol=1e-7)
 
 
+def test_harris_invariants_and_numpy_crosscheck(oracle):
+    """cv::cornerHarris (FeatureDetectorANMS's detection_use_harris_corner_): 0 on a flat image, negative on a
+    straight edge (det 0, trace > 0), and a float64 restatement of a c - b^2 - k (a + c)^2 elsewhere."""
+    assert (oracle.corner_harris(np.full((20, 30), 9, np.uint8)) == 0).all()
+    edge = np.tile(np.r_[np.zeros(10), np.full(10, 200)].astype(np.uint8), (16, 1))
+    r = oracle.corner_harris(edge, k=0.04)
+    assert (r <= 0).all() and (r[:, 8:12] < 0).all() and (r[:, :7] == 0).all()
+    rng = np.random.default_rng(7)
+    for shape, bs in (((24, 28), 3), ((25, 31), 4)):   # 31: three pixels a row take the scalar (double k) form
+        img = rng.integers(0, 256, shape).astype(np.uint8)
+        p = np.pad(img.astype(np.float64), 1, mode="reflect")
+        sc = 1.0 / (4 * bs * 255.0)
+        dx = ((p[:-2, 2:] - p[:-2, :-2]) + 2 * (p[1:-1, 2:] - p[1:-1, :-2]) + (p[2:, 2:] - p[2:, :-2])) * sc
+        dy = ((p[2:, :-2] - p[:-2, :-2]) + 2 * (p[2:, 1:-1] - p[:-2, 1:-1]) + (p[2:, 2:] - p[:-2, 2:])) * sc
+        hl = bs // 2   # cv's anchor: offsets -hl .. bs - 1 - hl
+
+        def box(a):
+            q = np.pad(a, ((hl, bs - 1 - hl), (hl, bs - 1 - hl)), mode="reflect")
+            return sum(q[j:j + a.shape[0], i:i + a.shape[1]] for j in range(bs) for i in range(bs))
+        a, b, c = box(dx * dx), box(dx * dy), box(dy * dy)
+        for k in (0.04, 0.15):
+            want = a * c - b * b - k * (a + c) ** 2
+            got = oracle.corner_harris(img, block_size=bs, k=k)
+            assert np.allclose(got, want, rtol=5e-3, atol=1e-9 + 2e-6 * np.abs(want).max())
+    # the ANMS detector's struct switches goodFeaturesToTrack to the Harris map
+    img = rng.integers(0, 256, (60, 80)).astype(np.uint8)
+    k0 = oracle.good_features_to_track(img, 50, 0.01, 3.0, block_size=4)
+    k1 = oracle.good_features_to_track(img, 50, 0.01, 3.0, block_size=4, use_harris=True, k=0.04)
+    assert len(k1) > 10 and not np.array_equal(k0, k1)
+    resp = oracle.corner_harris(img, block_size=4, k=0.04)
+    x, y = k1[0].astype(int)
+    assert resp[y, x] == resp[1:-1, 1:-1].max()
+
+
+def test_gftt_min_distance_is_greedy_in_response_order(oracle):
+    """cv's minDistance rule for values the bucketing detector never uses (FeatureDetectorANMS.cpp:24): corners
+    come out in descending response, no two closer than minDistance, and none that was dropped could be added."""
+    rng = np.random.default_rng(21)
+    img = rng.integers(0, 256, (90, 120)).astype(np.uint8)
+    lam = oracle.corner_min_eigen_val(img, block_size=4)
+    allk = oracle.good_features_to_track(img, 100000, 0.01, 1.0, block_size=4)
+    for md in (1.0, 1.2, 2.0, 4.5, 9.0):
+        kp = oracle.good_features_to_track(img, 100000, 0.01, md, block_size=4).astype(int)
+        v = lam[kp[:, 1], kp[:, 0]]
+        assert (np.diff(v) <= 0).all()
+        d2 = ((kp[:, None, :] - kp[None, :, :]) ** 2).sum(-1) + np.eye(len(kp), dtype=int) * 10 ** 6
+        assert (d2 >= md * md).all()
+        if md == 1.0:
+            assert len(kp) == len(allk)
+        else:
+            kept = {tuple(p) for p in kp}
+            for p in allk.astype(int):
+                if tuple(p) not in kept:   # dropped: a kept corner with at least its response lies within md
+                    near = ((kp - p) ** 2).sum(-1) < md * md
+                    assert (lam[kp[near, 1], kp[near, 0]] >= lam[p[1], p[0]]).any()
+
+
 def test_min_eig_roi_reads_parent_pixels(oracle):
     rng = np.random.default_rng(3)
     img = rng.integers(0, 256, (40, 60)).astype(np.uint8)

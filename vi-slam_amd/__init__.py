@@ -49,6 +49,7 @@ class VsfParams(C.Structure):
         ("anms_ignore_edge", C.c_int32), ("anms_tolerance", C.c_double),
         ("tracker_kind", C.c_int32), ("lssd_levels", C.c_int32), ("lssd_max_iterations", C.c_int32),
         ("lssd_max_recovered_dist", C.c_double), ("lk_cache_max_bytes", C.c_int64),
+        ("anms_detection_min_distance", C.c_double), ("anms_use_harris", C.c_int32), ("anms_harris_k", C.c_double),
     ]
 
 
@@ -525,8 +526,6 @@ class FeatureDetectorANMS:
             self.non_max_suppression_tolerance_ = 0.1
 
     def __init__(self, parameter, width, height, device_id=0, capacity=0):
-        if parameter.detection_use_harris_corner_ or parameter.detection_min_feature_distance_ != 1.0:
-            raise VsfError(-1, "Harris scoring / detection_min_feature_distance_ != 1.0 are not supported")
         p = default_params(detector_kind=DETECTOR_ANMS, max_features=parameter.max_feature_number_,
                            min_distance=parameter.min_feature_distance_,
                            anms_detection_features=parameter.detection_feature_number_,
@@ -534,6 +533,9 @@ class FeatureDetectorANMS:
                            anms_block_size=parameter.detection_block_size_,
                            anms_ignore_edge=parameter.detection_ignore_edge_,
                            anms_tolerance=parameter.non_max_suppression_tolerance_,
+                           anms_detection_min_distance=parameter.detection_min_feature_distance_,
+                           anms_use_harris=1 if parameter.detection_use_harris_corner_ else 0,
+                           anms_harris_k=parameter.detection_k_,
                            width=width, height=height, device_id=device_id, capacity=capacity)
         self.parameter_ = parameter
         self.ctx = Context(p)

@@ -26,6 +26,10 @@ struct AnmsParams {
   int hash_bits;
   int cand_cap;      // candidate keys kept per stream
   double quality;    // detection_quality_level_
+  // detection_min_feature_distance_ > 1 (cv's greedy minDistance rule, anms_topk_kernel<true>)
+  int gcap;          // keys of a sorted chunk (power of two >= kcap)
+  int grad;          // ceil(minDistance): half side of the square that holds the suppression disc
+  double gmd2;       // minDistance squared, as cv squares it (double)
   int halfw[ANMS_MAX_RADIUS + 1];  // cv::Circle half widths: disc = { |dy| <= r, |dx| <= halfw[|dy|] }
 };
 
@@ -94,7 +98,7 @@ __device__ __forceinline__ unsigned long long anms_key_from_map(const float* __r
   if (x < 1 || x >= w - 1 || y < 1 || y >= h - 1) return 0ull;
   float v = L[idx];
   v = v > thr ? v : 0.f;
-  if (v == 0.f) return 0ull;
+  if (!(v > 0.f)) return 0ull;
   float m = v;
 #pragma unroll
   for (int j = -1; j <= 1; j++)
@@ -105,6 +109,8 @@ __device__ __forceinline__ unsigned long long anms_key_from_map(const float* __r
       m = fmaxf(m, t);
     }
   if (v != m || !M[idx]) return 0ull;
+  // (v > 0: with a negative masked maximum -- Harris on an image of edges only -- cv's threshold max * quality,
+  // quality in [0, 1], is at or above that maximum, and no response at or below the maximum passes it)
   return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)idx;
 }
 
@@ -119,32 +125,56 @@ __device__ __forceinline__ unsigned long long anms_key_from_map(const float* __r
 //   * Keys are read four per thread and iteration (loads in flight together), and a wave adds the keys that
 //     share the bin of its first lane with ONE LDS atomic: the upper bytes of lambda are the same for most keys
 //     of a frame, and sixteen waves adding one by one to the same address queue behind each other.
+// GREEDY (detection_min_feature_distance_ > 1): cv::goodFeaturesToTrack visits the sorted corners and accepts one
+// when no accepted corner lies closer than minDistance (float dx*dx + dy*dy < double minDistance^2), until
+// maxCorners are accepted.  Here the sorted list is produced in chunks of gcap keys (the same select + sort, over
+// the keys below the previous chunk's smallest), and a chunk is swept a window of blockDim.x keys at a time: a
+// thread holds one key of the window and whether it is still alive; the first alive key of the window is accepted
+// (one ballot per wave, one LDS atomicMin, ONE barrier per accepted corner), every thread tests its own key against
+// it in registers, and the corner's disc is zeroed in the stream's flag image -- dead for the score kernel by now --
+// which is what tells later windows and chunks that a key is blocked.  The flag image read back by vsf_debug_anms
+// therefore has those discs zeroed too.
+template <bool GREEDY>
 __global__ __launch_bounds__(1024) void anms_topk_kernel(const float* __restrict__ lam, long long lam_sstride,
-                                                         const uint8_t* __restrict__ flag,
-                                                         const unsigned int* __restrict__ cell_max,
+                                                         uint8_t* flag, const unsigned int* __restrict__ cell_max,
                                                          const unsigned long long* __restrict__ cand,
                                                          const int* __restrict__ cand_cnt, AnmsParams ap,
                                                          short2* __restrict__ kp, int* __restrict__ ndet) {
   extern __shared__ __align__(16) uint8_t smem[];
-  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);  // [kcap]
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);  // [kcap], GREEDY: [gcap]
   __shared__ unsigned int s_hist[256];
   __shared__ unsigned long long s_prefix;
   __shared__ int s_remaining, s_count, s_stop, s_ncand;
+  __shared__ int s_first[3];
   const int NT = (int)blockDim.x, tid = (int)threadIdx.x;
   const int stream = blockIdx.x;
   const int total = cand_cnt[stream];
+  const unsigned int enc = cell_max[stream];
   const bool overflow = total > ap.cand_cap;
   const int M = overflow ? ap.w * ap.h : total;
   const float* L = lam + (long long)stream * lam_sstride;
-  const uint8_t* F = flag + (long long)stream * ap.w * ap.h;
+  uint8_t* F = flag + (long long)stream * ap.w * ap.h;
   const unsigned long long* C = cand + (long long)stream * ap.cand_cap;
-  const unsigned int enc = cell_max[stream];
   const float thr = (float)((enc ? (double)float_order_decode(enc) : 0.0) * ap.quality);
+  const int want = GREEDY ? ap.gcap : ap.nfeatures;   // keys of one sorted chunk
+  const int arr = GREEDY ? ap.gcap : ap.kcap;         // slots of s_key
+  short2* out = kp + (long long)stream * ap.kcap;
+  unsigned long long U = ~0ull;  // GREEDY: keys at or above U belong to earlier chunks
+  int accepted = 0;
   // the list holds every positive local maximum the score kernel could not rule out: cv's threshold is applied here
   auto key_at = [&](int i) -> unsigned long long {
-    if (overflow) return anms_key_from_map(L, ap.w, ap.h, thr, F, i);
-    const unsigned long long k = C[i];
-    return __uint_as_float((unsigned int)(k >> 32)) > thr ? k : 0ull;
+    unsigned long long k;
+    if (overflow) {
+      k = anms_key_from_map(L, ap.w, ap.h, thr, F, i);  // (reads the flag: blocked positions give no key)
+    } else {
+      k = C[i];
+      if (!(__uint_as_float((unsigned int)(k >> 32)) > thr)) k = 0ull;
+    }
+    if (GREEDY && U != ~0ull) {
+      if (k >= U) k = 0ull;
+      if (k != 0ull && !overflow && F[(unsigned int)k] == 0) k = 0ull;  // blocked by an accepted corner
+    }
+    return k;
   };
   // f(key) for every candidate key (0 = none), four independent reads per thread and iteration
   auto for_keys = [&](auto&& f) {
@@ -168,85 +198,133 @@ __global__ __launch_bounds__(1024) void anms_topk_kernel(const float* __restrict
     }
   };
 
-  unsigned long long T = 1ull;  // keys are never 0
-  int K = 0;
-  {
-    if (tid == 0) {
-      s_prefix = 0ull;
-      s_stop = 0;
-    }
-    unsigned long long himask = 0ull;
-    for (int b = 7; b >= 0; b--) {
-      for (int i = tid; i < 256; i += NT) s_hist[i] = 0u;
-      __syncthreads();
-      const unsigned long long prefix = s_prefix;
-      for_keys([&](unsigned long long k) {
-        if (k != 0ull && (k & himask) == prefix) hist_add((unsigned int)(k >> (8 * b)) & 255u);
-      });
-      __syncthreads();
+  for (;;) {  // one round per chunk; a single round unless GREEDY
+    unsigned long long T = 1ull;  // keys are never 0
+    int K = 0;
+    {
+      __syncthreads();  // (GREEDY: the discs of the chunk before are visible, the shared scalars are free)
       if (tid == 0) {
-        if (b == 7) {  // the first pass saw every key: the number of candidates
-          int nc = 0;
-          for (int q = 0; q < 256; q++) nc += (int)s_hist[q];
-          s_ncand = nc;
-          s_remaining = min(nc, ap.nfeatures);
-          if (nc <= ap.nfeatures) s_stop = 1;  // every key is kept: T stays 1
-        }
-        if (!s_stop) {
-          int rem = s_remaining, bin = 255;
-          for (; bin > 0; bin--) {
-            const int hcnt = (int)s_hist[bin];
-            if (hcnt >= rem) break;
-            rem -= hcnt;
+        s_prefix = 0ull;
+        s_stop = 0;
+      }
+      unsigned long long himask = 0ull;
+      for (int b = 7; b >= 0; b--) {
+        for (int i = tid; i < 256; i += NT) s_hist[i] = 0u;
+        __syncthreads();
+        const unsigned long long prefix = s_prefix;
+        for_keys([&](unsigned long long k) {
+          if (k != 0ull && (k & himask) == prefix) hist_add((unsigned int)(k >> (8 * b)) & 255u);
+        });
+        __syncthreads();
+        if (tid == 0) {
+          if (b == 7) {  // the first pass saw every key: the number of candidates
+            int nc = 0;
+            for (int q = 0; q < 256; q++) nc += (int)s_hist[q];
+            s_ncand = nc;
+            s_remaining = min(nc, want);
+            if (nc <= want) s_stop = 1;  // every key is kept: T stays 1
           }
-          s_prefix = prefix | ((unsigned long long)bin << (8 * b));
-          s_remaining = rem;
-          // the bin holds exactly the keys still wanted: all keys at or above the prefix are the top K
-          if ((int)s_hist[bin] == rem) s_stop = 2;
+          if (!s_stop) {
+            int rem = s_remaining, bin = 255;
+            for (; bin > 0; bin--) {
+              const int hcnt = (int)s_hist[bin];
+              if (hcnt >= rem) break;
+              rem -= hcnt;
+            }
+            s_prefix = prefix | ((unsigned long long)bin << (8 * b));
+            s_remaining = rem;
+            // the bin holds exactly the keys still wanted: all keys at or above the prefix are the top K
+            if ((int)s_hist[bin] == rem) s_stop = 2;
+          }
+        }
+        himask |= 0xffull << (8 * b);
+        __syncthreads();
+        if (s_stop) break;
+      }
+      K = min(s_ncand, want);
+      if (s_stop != 1) T = s_prefix;
+    }
+    const bool last_chunk = s_ncand <= want;
+    // gather and sort
+    __syncthreads();
+    for (int i = tid; i < arr; i += NT) s_key[i] = 0ull;
+    if (tid == 0) s_count = 0;
+    __syncthreads();
+    for_keys([&](unsigned long long k) {
+      if (k != 0ull && k >= T) {
+        const int slot = atomicAdd(&s_count, 1);
+        if (slot < arr) s_key[slot] = k;
+      }
+    });
+    __syncthreads();
+    // the slots beyond the gathered keys hold 0 and sort to the end: sort the smallest power of two that holds them
+    int n2 = 1;
+    while (n2 < K) n2 <<= 1;
+    for (int size = 2; size <= n2; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = tid; i < n2 / 2; i += NT) {
+          const int lo = ((i / stride) * stride * 2) + (i % stride), hi = lo + stride;
+          const bool desc = ((lo & size) == 0);
+          const unsigned long long a = s_key[lo], b2 = s_key[hi];
+          if (desc ? (a < b2) : (a > b2)) {
+            s_key[lo] = b2;
+            s_key[hi] = a;
+          }
+        }
+        __syncthreads();
+      }
+    if (!GREEDY) {
+      for (int i = tid; i < K; i += NT) {
+        const int idx = (int)(unsigned int)s_key[i];
+        const int y = idx / ap.w;
+        out[i] = make_short2((short)(idx - y * ap.w), (short)y);
+      }
+      if (tid == 0) ndet[stream] = K;
+      return;
+    }
+    // ---- GREEDY sweep of the sorted chunk
+    const int lane = tid & 63;
+    const int side = 2 * ap.grad + 1;
+    if (tid == 0) s_first[0] = s_first[1] = s_first[2] = 0x7fffffff;
+    int it = 0;  // s_first[it % 3] belongs to iteration `it`; the slot two iterations ahead is reset meanwhile
+    for (int cursor = 0; cursor < K && accepted < ap.nfeatures; cursor += NT) {
+      __syncthreads();  // the discs painted so far are visible (and s_first's initial values)
+      const int i = cursor + tid;
+      bool alive = false;
+      int mx = 0, my = 0;
+      if (i < K) {
+        const int idx = (int)(unsigned int)s_key[i];
+        my = idx / ap.w;
+        mx = idx - my * ap.w;
+        alive = F[idx] != 0;
+      }
+      while (accepted < ap.nfeatures) {
+        const int slot = it % 3;
+        const unsigned long long bal = __ballot(alive);
+        if (bal != 0ull && lane == 0) atomicMin(&s_first[slot], cursor + (tid & ~63) + __ffsll((long long)bal) - 1);
+        __syncthreads();
+        const int first = s_first[slot];
+        if (tid == 0) s_first[(it + 2) % 3] = 0x7fffffff;
+        it++;
+        if (first == 0x7fffffff) break;  // the window holds no alive key
+        const int pidx = (int)(unsigned int)s_key[first];
+        const int py = pidx / ap.w, px = pidx - py * ap.w;
+        if (tid == 0) out[accepted] = make_short2((short)px, (short)py);
+        accepted++;
+        const float ddx = (float)mx - (float)px, ddy = (float)my - (float)py;
+        if ((double)(ddx * ddx + ddy * ddy) < ap.gmd2) alive = false;  // (the accepted key itself: distance 0)
+        for (int t = tid; t < side * side; t += NT) {
+          const int dy = t / side - ap.grad, dx = t - (t / side) * side - ap.grad;
+          const int x = px + dx, y = py + dy;
+          const float fx = (float)dx, fy = (float)dy;
+          if (x >= 0 && x < ap.w && y >= 0 && y < ap.h && (double)(fx * fx + fy * fy) < ap.gmd2) F[y * ap.w + x] = 0;
         }
       }
-      himask |= 0xffull << (8 * b);
-      __syncthreads();
-      if (s_stop) break;
     }
-    K = min(s_ncand, ap.nfeatures);
-    if (s_stop != 1) T = s_prefix;
+    if (accepted >= ap.nfeatures || last_chunk) break;
+    U = s_key[K - 1];
   }
-  // gather and sort
-  __syncthreads();
-  for (int i = tid; i < ap.kcap; i += NT) s_key[i] = 0ull;
-  if (tid == 0) s_count = 0;
-  __syncthreads();
-  for_keys([&](unsigned long long k) {
-    if (k != 0ull && k >= T) {
-      const int slot = atomicAdd(&s_count, 1);
-      if (slot < ap.kcap) s_key[slot] = k;
-    }
-  });
-  __syncthreads();
-  // the slots beyond the gathered keys hold 0 and sort to the end: sort the smallest power of two that holds them
-  int n2 = 1;
-  while (n2 < K) n2 <<= 1;
-  for (int size = 2; size <= n2; size <<= 1)
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = tid; i < n2 / 2; i += NT) {
-        const int lo = ((i / stride) * stride * 2) + (i % stride), hi = lo + stride;
-        const bool desc = ((lo & size) == 0);
-        const unsigned long long a = s_key[lo], b2 = s_key[hi];
-        if (desc ? (a < b2) : (a > b2)) {
-          s_key[lo] = b2;
-          s_key[hi] = a;
-        }
-      }
-      __syncthreads();
-    }
-  short2* out = kp + (long long)stream * ap.kcap;
-  for (int i = tid; i < K; i += NT) {
-    const int idx = (int)(unsigned int)s_key[i];
-    const int y = idx / ap.w;
-    out[i] = make_short2((short)(idx - y * ap.w), (short)y);
-  }
-  if (tid == 0) ndet[stream] = K;
+  if (tid == 0) ndet[stream] = accepted;
 }
 
 // Position, before libstdc++'s std::sort, of the element std::sort leaves at position p when every

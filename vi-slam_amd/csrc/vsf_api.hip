@@ -524,13 +524,13 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
     ProfScope prof(c, VSF_K_SCORE, s);
     hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y * c->ncell, streams), dim3(256), 0, s, f.ptr, f.sstride,
                        f.pitch, W, H, masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, tiles_y, c->k_side,
-                       c->k_mid, c->p.quality_level, c->d_cellmax, c->d_cand, c->cand_cap, c->d_candcnt, 0);
+                       c->k_mid, c->p.quality_level, c->d_cellmax, c->d_cand, c->cand_cap, c->d_candcnt, 0, 0.0);
   }
   {  // cells whose candidate list overflowed (rare): their lambda map, for select_kernel's exact fallback
     ProfScope prof(c, VSF_K_CANDIDATES, s);
     hipLaunchKernelGGL(lam_fill_kernel<3>, dim3(c->ncell, streams), dim3(256), 0, s, f.ptr, f.sstride, f.pitch, W, H,
                        masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, tiles_y, c->k_side, c->k_mid, c->d_lam,
-                       c->d_cellmax, c->d_candcnt, c->cand_cap, -1);
+                       c->d_cellmax, c->d_candcnt, c->cand_cap, -1, 0.0);
   }
   {
     ProfScope prof(c, VSF_K_SELECT, s);
@@ -585,34 +585,43 @@ int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long l
   const long long fsz = (long long)W * H;
   {
     ProfScope prof(c, VSF_K_SCORE, s);
-    if (c->p.anms_block_size == 4)
-      hipLaunchKernelGGL(score_kernel<4>, dim3(streams, tiles_x * tiles_y), dim3(256), 0, s, f.ptr, f.sstride, f.pitch,
-                         W, H, c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, ap.quality,
-                         c->d_cellmax, c->d_acand, ap.cand_cap, c->d_candcnt, 1);
-    else
-      hipLaunchKernelGGL(score_kernel<3>, dim3(streams, tiles_x * tiles_y), dim3(256), 0, s, f.ptr, f.sstride, f.pitch,
-                         W, H, c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, ap.quality,
-                         c->d_cellmax, c->d_acand, ap.cand_cap, c->d_candcnt, 1);
+    auto launch = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(streams, tiles_x * tiles_y), dim3(256), 0, s, f.ptr, f.sstride, f.pitch, W, H,
+                         c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, ap.quality,
+                         c->d_cellmax, c->d_acand, ap.cand_cap, c->d_candcnt, 1, c->p.anms_harris_k);
+    };
+    const bool b4 = c->p.anms_block_size == 4, hr = c->p.anms_use_harris != 0;
+    if (b4 && !hr) launch(score_kernel<4, false>);
+    if (!b4 && !hr) launch(score_kernel<3, false>);
+    if (b4 && hr) launch(score_kernel<4, true>);
+    if (!b4 && hr) launch(score_kernel<3, true>);
   }
   {
     ProfScope prof(c, VSF_K_CANDIDATES, s);
-    if (c->p.anms_block_size == 4)
-      hipLaunchKernelGGL(lam_fill_kernel<4>, dim3(1, streams), dim3(256), 0, s, f.ptr, f.sstride, f.pitch, W, H,
-                         c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, c->d_lam,
-                         c->d_cellmax, c->d_candcnt, ap.cand_cap, -1);
-    else
-      hipLaunchKernelGGL(lam_fill_kernel<3>, dim3(1, streams), dim3(256), 0, s, f.ptr, f.sstride, f.pitch, W, H,
-                         c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, c->d_lam,
-                         c->d_cellmax, c->d_candcnt, ap.cand_cap, -1);
+    auto launch = [&](auto kern) {
+      hipLaunchKernelGGL(kern, dim3(1, streams), dim3(256), 0, s, f.ptr, f.sstride, f.pitch, W, H, c->d_aflag, fsz, W,
+                         G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, c->d_lam, c->d_cellmax, c->d_candcnt,
+                         ap.cand_cap, -1, c->p.anms_harris_k);
+    };
+    const bool b4 = c->p.anms_block_size == 4, hr = c->p.anms_use_harris != 0;
+    if (b4 && !hr) launch(lam_fill_kernel<4, false>);
+    if (!b4 && !hr) launch(lam_fill_kernel<3, false>);
+    if (b4 && hr) launch(lam_fill_kernel<4, true>);
+    if (!b4 && hr) launch(lam_fill_kernel<3, true>);
   }
   {
     ProfScope prof(c, VSF_K_SELECT, s);
     // one workgroup per stream in both kernels: few streams get large workgroups (a stream's few hundred thousand
     // keys behind 256 threads took 3.6 of C4 + ANMS's 10.6 ms per 32 frames), many streams fill the chip anyway
     const int nt = streams >= 1024 ? 256 : (streams >= 512 ? 512 : 1024);
-    hipLaunchKernelGGL(anms_topk_kernel, dim3(streams), dim3(nt), (size_t)ap.kcap * 8, s, c->d_lam,
-                       (long long)c->lam_total, c->d_aflag, c->d_cellmax, c->d_acand, c->d_candcnt, ap, c->d_akp,
-                       c->d_andet);
+    if (c->p.anms_detection_min_distance > 1.0)  // cv: minDistance >= 1 runs the distance test, which 1 never fails
+      hipLaunchKernelGGL(anms_topk_kernel<true>, dim3(streams), dim3(nt), (size_t)ap.gcap * 8, s, c->d_lam,
+                         (long long)c->lam_total, c->d_aflag, c->d_cellmax, c->d_acand, c->d_candcnt, ap, c->d_akp,
+                         c->d_andet);
+    else
+      hipLaunchKernelGGL(anms_topk_kernel<false>, dim3(streams), dim3(nt), (size_t)ap.kcap * 8, s, c->d_lam,
+                         (long long)c->lam_total, c->d_aflag, c->d_cellmax, c->d_acand, c->d_candcnt, ap, c->d_akp,
+                         c->d_andet);
     hipLaunchKernelGGL(anms_ssc_kernel, dim3(streams), dim3(nt), (size_t)anms_ssc_smem(ap), s, c->d_akp, c->d_andet,
                        c->d_n, ap, c->d_aselxy, c->d_aselcnt);
   }
@@ -852,6 +861,9 @@ void vsf_default_params(vsf_params* p) {
   p->anms_block_size = 4;
   p->anms_ignore_edge = 20;
   p->anms_tolerance = 0.1;
+  p->anms_detection_min_distance = 1.0;
+  p->anms_use_harris = 0;
+  p->anms_harris_k = 0.04;
   p->tracker_kind = VSF_TRACKER_LK;
   p->lssd_levels = 3;
   p->lssd_max_iterations = 5;
@@ -929,6 +941,9 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
         p->anms_ignore_edge < 0)
       return VSF_E_INVALID;
     if (p->width > 32767 || p->height > 32767) return VSF_E_INVALID;  // keypoints travel as short2
+    // cv's minDistance: anything up to 1 (0 and negatives included) never rejects a corner
+    if (!(p->anms_detection_min_distance <= (double)ANMS_MAX_RADIUS)) return VSF_E_INVALID;
+    if (p->anms_use_harris && !std::isfinite(p->anms_harris_k)) return VSF_E_INVALID;
     if ((long long)sc_tiles(p->width, SC_IW) * sc_tiles(p->height, SC_IH) > 65535) return VSF_E_INVALID;  // grid.y
   }
   const bool use_lssd = p->tracker_kind == VSF_TRACKER_LSSD;
@@ -1035,6 +1050,9 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     a.cand_cap = (p->width * p->height) / 6;
     if (a.cand_cap < 4096) a.cand_cap = 4096;
     a.quality = p->anms_quality_level;
+    a.gcap = a.kcap < 4096 ? 4096 : a.kcap;
+    a.grad = (int)std::ceil(p->anms_detection_min_distance > 1.0 ? p->anms_detection_min_distance : 1.0);
+    a.gmd2 = p->anms_detection_min_distance * p->anms_detection_min_distance;
     {  // cv::Circle (drawing.cpp), fill: midpoint walk; span on rows +-dy is +-dx and on rows +-dx is +-dy
       for (int i = 0; i <= ANMS_MAX_RADIUS; i++) a.halfw[i] = -1;
       int err = 0, dx = a.radius, dy = 0, plus = 1, minus = (a.radius << 1) - 1;
@@ -1161,7 +1179,8 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     acc(raise_dynamic_lds(reinterpret_cast<const void*>(append_kernel), 2, app_sm));
     if (use_anms) {
       acc(raise_dynamic_lds(reinterpret_cast<const void*>(anms_ssc_kernel), 3, anms_ssc_smem(c->anms)));
-      acc(raise_dynamic_lds(reinterpret_cast<const void*>(anms_topk_kernel), 4, c->anms.kcap * 8));
+      acc(raise_dynamic_lds(reinterpret_cast<const void*>(anms_topk_kernel<false>), 4, c->anms.kcap * 8));
+      acc(raise_dynamic_lds(reinterpret_cast<const void*>(anms_topk_kernel<true>), 5, c->anms.gcap * 8));
     }
     if (use_anms) {
       const int4 r = make_int4(0, 0, p->width, p->height);
@@ -1562,6 +1581,8 @@ int vsf_debug_lk(vsf_ctx* c, const uint8_t* prev, const uint8_t* next, int32_t w
 int vsf_debug_set_cand_cap(vsf_ctx* c, int32_t slots) {
   if (!c || slots < 16) return VSF_E_INVALID;
   c->cand_cap = slots < c->cand_cap_alloc ? slots : c->cand_cap_alloc;
+  // (the ANMS detector's whole-frame list only ever shrinks: its buffer was sized at creation)
+  if (c->p.detector_kind == VSF_DETECTOR_ANMS && slots < c->anms.cand_cap) c->anms.cand_cap = slots;
   return VSF_OK;
 }
 
@@ -1580,7 +1601,7 @@ int vsf_debug_min_eig(vsf_ctx* c, const uint8_t* img, int32_t w, int32_t h, int3
   // the map of this one cell through the score kernels' own tile routine; the feature table is not touched
   hipLaunchKernelGGL(lam_fill_kernel<3>, dim3(c->ncell, 1), dim3(256), 0, nullptr, f.ptr, f.sstride, f.pitch, w, h,
                      (const uint8_t*)nullptr, 0ll, 0, G, c->d_nact, tiles_x, tiles_y, c->k_side, c->k_mid, c->d_lam,
-                     c->d_cellmax, c->d_candcnt, c->cand_cap, cell);
+                     c->d_cellmax, c->d_candcnt, c->cand_cap, cell, 0.0);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipStreamSynchronize(nullptr));
   std::vector<int4> rects(c->ncell);

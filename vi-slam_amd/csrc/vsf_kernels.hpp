@@ -438,13 +438,16 @@ __host__ __device__ inline int sc_tiles(int cells_extent, int step) {
 // BS = blockSize of the box filter: 3 (offsets -1..+1; cv::goodFeaturesToTrack default, the bucketing
 // detector) or 4 (offsets -2..+1: anchor = blockSize / 2; the ANMS detector's GFTTDetector).
 // WRITE_LAM: also store the lambda block to the cell's map (fallback / debug); EMIT: emit candidate keys.
-template <int BS, bool WRITE_LAM, bool EMIT>
+// HARRIS: the response is cv::cornerHarris's a c - b^2 - k (a + c)^2 instead of the smaller eigenvalue (the ANMS
+// detector's detection_use_harris_corner_ / detection_k_, FeatureDetectorANMS.cpp:27-28, :41-47); everything
+// before and after the per-pixel formula is shared.
+template <int BS, bool WRITE_LAM, bool EMIT, bool HARRIS = false>
 __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int row_stride, int w, int h,
                                            const uint8_t* __restrict__ M, int mask_row_stride, int4 rc, int tx, int ty,
                                            float k_side, float k_mid, float* __restrict__ lam_cell,
                                            unsigned int* __restrict__ cmax, double quality,
                                            unsigned long long* __restrict__ cand, int cand_cap,
-                                           int* __restrict__ ccnt) {
+                                           int* __restrict__ ccnt, double harris_k = 0.0) {
   constexpr int HL = BS / 2, HR = BS - 1 - HL;             // covariance halo left/top, right/bottom
   constexpr int CW = SC_TW + HL + HR, CH = SC_TH + HL + HR;  // covariance tile
   constexpr int IW = CW + 2, IH = CH + 2;                  // staged image tile (Sobel reads +-1 more)
@@ -618,6 +621,25 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // lam_p / msk_p: the lambda-block / mask slot the value goes to (strip threads pass a base + constant offset)
   auto finish = [&](int x, int y, const double (&sum)[3], bool mk, float* lam_p, uint8_t* msk_p) {
     const int cx = cx0 + x, cy = cy0 + y;
+    if (HARRIS) {
+      // cv's calcHarris: groups of four pixels of a row in float32 with (float)k, products left to right; the last
+      // width % 4 pixels of the row with k as a double (the oracle's corner_response states both forms).  The
+      // response may be negative, so nothing is skipped and 0 stands in for nothing.
+      const float a = (float)sum[0], b = (float)sum[1], c = (float)sum[2];
+      const float ac_bb = a * c - b * b, t = a + c;
+      float lm;
+      if (cx < (cw & ~3))
+        lm = ac_bb - (float)harris_k * t * t;
+      else
+        lm = (float)((double)ac_bb - harris_k * (double)t * (double)t);
+      if (WRITE_LAM) lam_cell[cy * cw + cx] = lm;
+      if (EMIT) {
+        *lam_p = lm;
+        *msk_p = mk ? 1 : 0;
+      }
+      local_maxf = fmaxf(local_maxf, mk ? lm : -INFINITY);
+      return;
+    }
     const float a = (float)sum[0] * 0.5f, b = (float)sum[1], c = (float)sum[2] * 0.5f;
     // lambda <= a + c.  Where a + c is not above quality * (the cell maximum seen at block start) the pixel passes
     // neither the final threshold nor the maximum, and as a neighbour any value below a surviving candidate's
@@ -759,7 +781,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
 // with one returning atomic on its cell's counter, and with the tiles of ONE cell in flight together a few hundred
 // blocks queue on one address (the L2's same-address atomic rate: 1.67 against 1.30 ms per 1024 frames, measured on
 // the former separate candidates kernel).
-template <int BS>
+template <int BS, bool HARRIS = false>
 __global__ __launch_bounds__(256, (BS == 4 ? 7 : 8)) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
                                                     int row_stride, int w, int h,
                                                     const uint8_t* __restrict__ masks, long long mask_sstride,
@@ -768,7 +790,8 @@ __global__ __launch_bounds__(256, (BS == 4 ? 7 : 8)) void score_kernel(const uin
                                                     float k_side, float k_mid, double quality,
                                                     unsigned int* __restrict__ cell_max,
                                                     unsigned long long* __restrict__ cand, int cand_cap,
-                                                    int* __restrict__ cand_cnt, int stream_major) {
+                                                    int* __restrict__ cand_cnt, int stream_major,
+                                                    double harris_k) {
   const int stream = stream_major ? blockIdx.x : blockIdx.y;
   const int tc = stream_major ? blockIdx.y : blockIdx.x;
   const int tpc = tiles_x * tiles_y;
@@ -776,16 +799,19 @@ __global__ __launch_bounds__(256, (BS == 4 ? 7 : 8)) void score_kernel(const uin
   if (cell >= n_active[stream]) return;
   const int sc = stream * G.ncell + cell;
   const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-  score_tile<BS, false, true>(frames + (long long)stream * frame_sstride, row_stride, w, h,
-                              masks ? masks + (long long)stream * mask_sstride : nullptr, mask_row_stride,
-                              G.rects[cell], tx, ty, k_side, k_mid, nullptr, cell_max + sc, quality,
-                              cand + (long long)sc * cand_cap, cand_cap, cand_cnt + sc);
+  score_tile<BS, false, true, HARRIS>(frames + (long long)stream * frame_sstride, row_stride, w, h,
+                                      masks ? masks + (long long)stream * mask_sstride : nullptr, mask_row_stride,
+                                      G.rects[cell], tx, ty, k_side, k_mid, nullptr, cell_max + sc, quality,
+                                      cand + (long long)sc * cand_cap, cand_cap, cand_cnt + sc, harris_k);
 }
 
 // The lambda map of the cells whose candidate list overflowed (select_kernel / anms_topk_kernel then re-derive the
 // candidates from the map: exact, slow), or of ONE cell regardless (force_cell >= 0: vsf_debug_min_eig).  Same tile
 // routine, so the same arithmetic.  Grid: (cells, streams); a block walks the tiles of its cell.
-template <int BS>
+// (HARRIS: a negative masked maximum -- an image of edges only -- needs nothing special: cv's threshold
+// max * quality, quality in [0, 1], is then at or above the maximum, so no response passes it; the candidate list
+// holds positive local maxima only and is empty as well.)
+template <int BS, bool HARRIS = false>
 __global__ __launch_bounds__(256) void lam_fill_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
                                                        int row_stride, int w, int h,
                                                        const uint8_t* __restrict__ masks, long long mask_sstride,
@@ -793,7 +819,8 @@ __global__ __launch_bounds__(256) void lam_fill_kernel(const uint8_t* __restrict
                                                        const int* __restrict__ n_active, int tiles_x, int tiles_y,
                                                        float k_side, float k_mid, float* __restrict__ lam,
                                                        unsigned int* __restrict__ cell_max,
-                                                       const int* __restrict__ cand_cnt, int cand_cap, int force_cell) {
+                                                       const int* __restrict__ cand_cnt, int cand_cap, int force_cell,
+                                                       double harris_k) {
   const int stream = blockIdx.y, cell = blockIdx.x;
   const int sc = stream * G.ncell + cell;
   if (force_cell >= 0) {
@@ -804,9 +831,10 @@ __global__ __launch_bounds__(256) void lam_fill_kernel(const uint8_t* __restrict
   float* lam_cell = lam + (long long)stream * G.lam_total + G.lam_off[cell];
   for (int t = 0; t < tiles_x * tiles_y; t++) {
     const int ty = t / tiles_x, tx = t - ty * tiles_x;
-    score_tile<BS, true, false>(frames + (long long)stream * frame_sstride, row_stride, w, h,
-                                masks ? masks + (long long)stream * mask_sstride : nullptr, mask_row_stride,
-                                G.rects[cell], tx, ty, k_side, k_mid, lam_cell, cell_max + sc, 0.0, nullptr, 0, nullptr);
+    score_tile<BS, true, false, HARRIS>(frames + (long long)stream * frame_sstride, row_stride, w, h,
+                                        masks ? masks + (long long)stream * mask_sstride : nullptr, mask_row_stride,
+                                        G.rects[cell], tx, ty, k_side, k_mid, lam_cell, cell_max + sc, 0.0, nullptr, 0,
+                                        nullptr, harris_k);
     __syncthreads();  // the tile's LDS is reused by the next one
   }
 }

@@ -216,10 +216,7 @@ class FeatureDetectorANMS : public FeatureDetectorBase {
   };
 
   explicit FeatureDetectorANMS(const Parameter parameter, int device_id = 0)
-      : parameter_(parameter), device_id_(device_id) {
-    if (parameter_.detection_use_harris_corner_ || parameter_.detection_min_feature_distance_ != 1.0)
-      throw std::runtime_error("FeatureDetectorANMS: Harris scoring / detection_min_feature_distance_ != 1 unsupported");
-  }
+      : parameter_(parameter), device_id_(device_id) {}
 
   void UpdateDetection(FeaturePositionDatabase& feature_position, FeatureAgeDatabase& feature_age,
                        const ImageView& current_image, const ImageView& mask_image = ImageView()) override {
@@ -264,6 +261,9 @@ class FeatureDetectorANMS : public FeatureDetectorBase {
     p.anms_block_size = parameter_.detection_block_size_;
     p.anms_ignore_edge = parameter_.detection_ignore_edge_;
     p.anms_tolerance = parameter_.non_max_suppression_tolerance_;
+    p.anms_detection_min_distance = parameter_.detection_min_feature_distance_;
+    p.anms_use_harris = parameter_.detection_use_harris_corner_ ? 1 : 0;
+    p.anms_harris_k = parameter_.detection_k_;
     p.width = w;
     p.height = h;
     p.device_id = device_id_;
