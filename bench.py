@@ -212,7 +212,9 @@ def run_workload(vsf, mg, name, args, env, steps, warmup, preroll, streams=0, ke
                            klt_eps=0.01, backtrack_thr=1.0, width=W, height=H, streams=B,
                            device_id=local_rank,
                            detector_kind=vsf.DETECTOR_ANMS if args.detector == "anms" else vsf.DETECTOR_BUCKETING,
-                           tracker_kind=vsf.TRACKER_LSSD if args.tracker == "lssd" else vsf.TRACKER_LK)
+                           tracker_kind=vsf.TRACKER_LSSD if args.tracker == "lssd" else vsf.TRACKER_LK,
+                           anms_detection_min_distance=args.anms_min_distance,
+                           anms_use_harris=1 if args.anms_harris else 0)
     ctx = vsf.Context(p)
     cap = ctx.capacity
     stream = torch.cuda.current_stream().cuda_stream
@@ -342,6 +344,9 @@ def main():
                     help="run the collective through torch.distributed instead of the library's vsf_gather_tracks")
     ap.add_argument("--detector", choices=("bucketing", "anms"), default="bucketing",
                     help="FeatureDetectorShiTomasiBucketing (the headline configuration) or FeatureDetectorANMS")
+    ap.add_argument("--anms-min-distance", type=float, default=1.0,
+                    help="with --detector anms: detection_min_feature_distance_ (above 1: cv's greedy rule)")
+    ap.add_argument("--anms-harris", action="store_true", help="with --detector anms: Harris response")
     ap.add_argument("--tracker", choices=("lk", "lssd"), default="lk",
                     help="FeatureTrackerLucasKanade (the headline configuration) or FeatureTrackerLSSDLucasKanade")
     args = ap.parse_args()
@@ -495,9 +500,14 @@ def cpu_baseline(frames, order, cfg):
     (sa, ka), (s1, k1) = cfg["cpu"]
     va, ta, sa, ka, da = leg(sa, ka, 0)
     v1, t1, s1, k1, d1 = leg(s1, k1, 1)
+    # ONE stream on all cores: threads over the rows of the pyramid / derivative / response images and over the
+    # points of the LK call, the way OpenCV's parallel_for_ spends the cores of the reference's single camera
+    vl, tl, sl, kl, dl = leg(1, 4 * k1, 0)
     return {"value": va, "unit": "frames/s", "cores": ta, "kind": "port",
             "single_thread": {"value": v1, "cores": t1,
                               "sample": "%d streams x %d steps, %.1f s" % (s1, k1, d1)},
+            "single_stream": {"value": vl, "ms_per_frame": 1e3 / vl, "cores": tl,
+                              "sample": "1 stream x %d steps, OpenMP over rows and points, %.1f s" % (kl, dl)},
             "sample": "%d streams x %d steps of the same workload, CPU oracle (restated reference CPU path, "
                       "gcc -O3 -march=x86-64-v3 -ffp-contract=off, OpenMP over streams), %.1f s; timed from the second frame "
                       "on, i.e. including the cheaper start-up transient the GPU line's pre-roll skips" % (sa, ka, da)}

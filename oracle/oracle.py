@@ -466,7 +466,8 @@ class StreamsBaseline:
 
     @property
     def threads(self):
-        return min(self.L.orc_num_threads(), self.streams)
+        # several streams: one thread per stream at most; ONE stream: the row / point loops take every thread
+        return self.L.orc_num_threads() if self.streams == 1 else min(self.L.orc_num_threads(), self.streams)
 
     def step(self, frames):
         frames = np.ascontiguousarray(frames, np.uint8)

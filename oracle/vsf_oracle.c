@@ -46,7 +46,13 @@ static inline int cv_floor_f(float v) { return (int)floorf(v); }
 /* ------------------------------------------------------------------------------------------ */
 void orc_pyr_down_u8(const uint8_t* src, int w, int h, int stride, uint8_t* dst) {
   const int dw = (w + 1) / 2, dh = (h + 1) / 2;
+  /* Rows are independent: threads share them when the caller is not already inside a parallel region (OpenMP
+   * leaves a nested region with one thread), which is how the single-stream CPU baseline uses its cores --
+   * OpenCV's parallel_for_ over rows / points.  Same arithmetic per row either way. */
+#pragma omp parallel if (dh >= 32)
+  {
   int* rows = (int*)malloc(sizeof(int) * (size_t)dw * 5);
+#pragma omp for schedule(static)
   for (int y = 0; y < dh; y++) {
     for (int k = 0; k < 5; k++) {
       const int sy = reflect101(2 * y - 2 + k, h);
@@ -66,6 +72,7 @@ void orc_pyr_down_u8(const uint8_t* src, int w, int h, int stride, uint8_t* dst)
     }
   }
   free(rows);
+  }
 }
 
 /* cv: buildOpticalFlowPyramid(img, pyr, winSize, maxLevel, withDerivatives=false).
@@ -106,8 +113,11 @@ void orc_free_pyramid(orc_pyramid* p) {
 
 /* cv: calcSharrDeriv (video/lkpyramid.cpp) -- SURVEY A.3.  dxy is interleaved (Ix, Iy) int16. */
 void orc_scharr_s16(const uint8_t* src, int w, int h, int stride, int16_t* dxy) {
+#pragma omp parallel if (h >= 32)
+  {
   int* t0 = (int*)malloc(sizeof(int) * (size_t)(w + 2) * 2);
   int* t1 = t0 + (w + 2);
+#pragma omp for schedule(static)
   for (int y = 0; y < h; y++) {
     const uint8_t* r0 = src + (size_t)(y > 0 ? y - 1 : (h > 1 ? 1 : 0)) * stride;
     const uint8_t* r1 = src + (size_t)y * stride;
@@ -128,6 +138,7 @@ void orc_scharr_s16(const uint8_t* src, int w, int h, int stride, int16_t* dxy) 
     }
   }
   free(t0);
+  }
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -148,10 +159,16 @@ long long orc_dbg_iters = 0, orc_dbg_level_passes = 0, orc_dbg_restage_moves = 0
 static void lk_level(const orc_level* I, const int16_t* dI, const orc_level* J,
                      const float* prev_pts, float* next_pts, uint8_t* status, float* err, int n,
                      int win, int level, int max_level, int max_count, double epsilon,
-                     double min_eig_thr, int acc_mode, int16_t* Iw, int16_t* dIw) {
+                     double min_eig_thr, int acc_mode) {
   const float half = (win - 1) * 0.5f;
   const float FLT_SCALE = 1.f / (1 << 20);
   const int W_BITS = 14;
+  /* points are independent (cv: parallel_for_ over the points, LKTrackerInvoker) */
+#pragma omp parallel if (n >= 8)
+  {
+  int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)win * win * 3);
+  int16_t* dIw = Iw + (size_t)win * win;
+#pragma omp for schedule(dynamic, 4)
   for (int i = 0; i < n; i++) {
     float px = prev_pts[2 * i] * (float)(1. / (1 << level));
     float py = prev_pts[2 * i + 1] * (float)(1. / (1 << level));
@@ -229,9 +246,11 @@ static void lk_level(const orc_level* I, const int16_t* dI, const orc_level* J,
     nx -= half;
     ny -= half;
     float pdx = 0, pdy = 0;
+#pragma omp atomic
     orc_dbg_level_passes++;
     for (int j = 0; j < max_count; j++) {
       int inx = cv_floor_f(nx), iny = cv_floor_f(ny);
+#pragma omp atomic
       orc_dbg_iters++;
       if (inx < -win || inx >= J->w || iny < -win || iny >= J->h) {
         if (level == 0) status[i] = 0;
@@ -307,6 +326,8 @@ static void lk_level(const orc_level* I, const int16_t* dI, const orc_level* J,
       err[i] = errval * 1.f / (32 * win * win);
     }
   }
+  free(Iw);
+  }
 }
 
 int orc_calc_optical_flow_pyr_lk(const uint8_t* prev, int prev_stride, const uint8_t* next,
@@ -330,17 +351,14 @@ int orc_calc_optical_flow_pyr_lk(const uint8_t* prev, int prev_stride, const uin
     status[i] = 1;
     if (err) err[i] = 0;
   }
-  int16_t* Iw = (int16_t*)malloc(sizeof(int16_t) * (size_t)win * win * 3);
-  int16_t* dIw = Iw + (size_t)win * win;
   int16_t* deriv = (int16_t*)malloc(sizeof(int16_t) * 2 * (size_t)w * h);
   for (int level = ml; level >= 0; level--) {
     const orc_level* I = &P.lv[level];
     orc_scharr_s16(I->data, I->w, I->h, I->w, deriv);
     lk_level(I, deriv, &N.lv[level], prev_pts, next_pts, status, err, n, win, level, ml, max_count,
-             eps, min_eig_thr, acc_mode, Iw, dIw);
+             eps, min_eig_thr, acc_mode);
   }
   free(deriv);
-  free(Iw);
   orc_free_pyramid(&P);
   orc_free_pyramid(&N);
   return ml;
@@ -364,6 +382,7 @@ static void corner_response(const uint8_t* img, int img_w, int img_h, int stride
   const double scale_d = 1.0 / ((double)(1 << 2) * block_size * 255.0);
   const float k_side = (float)(1.0 * scale_d), k_mid = (float)(2.0 * scale_d);
   float* cov = (float*)malloc(sizeof(float) * 3 * (size_t)rw * rh);
+#pragma omp parallel for schedule(static) if (rh >= 32)
   for (int y = 0; y < rh; y++) {
     const int Y = ry + y;
     const int ym = reflect101(Y - 1, img_h), yp = reflect101(Y + 1, img_h);
@@ -390,6 +409,7 @@ static void corner_response(const uint8_t* img, int img_w, int img_h, int stride
     }
   }
   const int a0 = -(block_size / 2); /* anchor = block/2: offsets a0 .. a0+block-1 */
+#pragma omp parallel for schedule(static) if (rh >= 32)
   for (int y = 0; y < rh; y++) {
     for (int x = 0; x < rw; x++) {
       double s[3] = {0, 0, 0};
@@ -1731,8 +1751,9 @@ int orc_step_streams(orc_tracker* trackers, orc_detector* detectors, int streams
                      const uint8_t* frames, long frame_stride_bytes, int w, int h, int stride,
                      uint64_t* ids, double* xy, uint32_t* age, int* n, int capacity) {
   int rc_all = 0;
+  /* one stream: no team here, so that the row / point loops inside get the cores (single-stream latency) */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel for schedule(dynamic, 1) if (streams > 1)
 #endif
   for (int s = 0; s < streams; s++) {
     const uint8_t* f = frames + (size_t)s * frame_stride_bytes;

@@ -4,7 +4,8 @@
 // pytest wrapper (tests/test_gpu_cpp_mirror.py) compares them with the CPU oracle.
 //   usage: frontend_mirror_main frames.raw W H N out.txt rows cols maxN minDist iter eps win lvl back
 // rows == 0 selects FeatureDetectorANMS (Parameter defaults with max_feature_number_ = maxN,
-// min_feature_distance_ = minDist, detection_feature_number_ = 2 * maxN) instead of the bucketing detector.
+// min_feature_distance_ = minDist, detection_feature_number_ = 2 * maxN) instead of the bucketing detector;
+// with cols == 1 also detection_use_harris_corner_, detection_k_ = 0.06, detection_min_feature_distance_ = 3.5.
 // iter == 0 selects FeatureTrackerLSSDLucasKanade (Parameter defaults) driven the way
 // KimeraFrontend.cpp drives a tracker: the 3-argument Track on every frame, then the detector.
 #include <cstdio>
@@ -34,6 +35,11 @@ int main(int argc, char** argv) {
       prm.max_feature_number_ = std::atoi(argv[8]);
       prm.min_feature_distance_ = std::atof(argv[9]);
       prm.detection_feature_number_ = prm.max_feature_number_ * 2;
+      if (std::atoi(argv[7]) == 1) {
+        prm.detection_use_harris_corner_ = true;
+        prm.detection_k_ = 0.06;
+        prm.detection_min_feature_distance_ = 3.5;
+      }
       auto* d = new vslam::feature::FeatureDetectorANMS(prm);
       detector_ptr.reset(d);
       max_index = [d]() { return d->max_feature_index(); };

@@ -14,8 +14,15 @@ def test_mirror_binary_is_built():
     assert os.path.exists(EXE), "run __graft_entry__.build()"
 
 
+def _oracle_detector(oracle, det_args):
+    if det_args[0]:
+        return oracle.Detector(*det_args)
+    kw = dict(detection_use_harris_corner=1, detection_k=0.06, detection_min_feature_distance=3.5) if det_args[1] else {}
+    return oracle.AnmsDetector(det_args[2], det_args[3], **kw)
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("det_args", [(3, 3, 180, 5.0), (0, 0, 120, 9.0)])
+@pytest.mark.parametrize("det_args", [(3, 3, 180, 5.0), (0, 0, 120, 9.0), (0, 1, 120, 9.0)])
 def test_cpp_mirror_matches_oracle(oracle, synth, tmp_path, det_args):
     w, h, n = 400, 300, 5
     frames, _ = synth.sequence(77, w, h, n)
@@ -31,7 +38,7 @@ def test_cpp_mirror_matches_oracle(oracle, synth, tmp_path, det_args):
             got.append(cur)
         else:
             cur["tab"][int(p[0])] = (float(p[1]), float(p[2]), int(p[3]))
-    det = oracle.Detector(*det_args) if det_args[0] else oracle.AnmsDetector(det_args[2], det_args[3])
+    det = _oracle_detector(oracle, det_args)
     trk, tab = oracle.Tracker(*trk_args, oracle.ACC_EXACT), oracle.FeatureTable(1024)
     for k in range(n):
         if k == 0:
@@ -64,7 +71,7 @@ def test_cpp_mirror_lssd_tracker_matches_oracle(oracle, synth, tmp_path, det_arg
             got.append(cur)
         else:
             cur["tab"][int(p[0])] = (float(p[1]), float(p[2]), int(p[3]))
-    det = oracle.Detector(*det_args) if det_args[0] else oracle.AnmsDetector(det_args[2], det_args[3])
+    det = _oracle_detector(oracle, det_args)
     trk, tab = oracle.LssdTracker(mode=oracle.LSSD_TREE), oracle.FeatureTable(1024)
     for k in range(n):
         trk.track(tab, frames[k])
