@@ -422,7 +422,15 @@ __device__ __forceinline__ float float_order_decode(unsigned int e) {
 //     block's own maximum, a lower bound of the final one) can never pass and are dropped at once.
 //   * Sobel reads the parent image's real pixels (REFLECT_101 only at the true image border); the box filter
 //     reflects at the CELL border and sums in double like cv::boxFilter does for 32F input.
-constexpr int SC_TW = 64, SC_TH = 16;          // lambda block of a tile
+// (Round 3 measured 32-row tiles in blocks of 512 threads: 11 % fewer lambda rows, 16 % fewer covariance rows per
+// candidate, the same waves per CU -- and 1.50 against 1.31 ms per 1024 frames at C2, 3.25 against 2.52 ms with the
+// ANMS detector: eight waves meeting at every barrier and four blocks a CU to overlap their phases cost more than
+// the halo rows saved.  -DVSF_SC_TH=32 still builds and passes the parity tests.)
+#ifndef VSF_SC_TH
+#define VSF_SC_TH 16
+#endif
+constexpr int SC_TW = 64, SC_TH = VSF_SC_TH;   // lambda block of a tile (16 or 32 rows)
+constexpr int SC_NT = SC_TW * SC_TH / 4;       // threads of a block: four lambda rows of one column per thread
 constexpr int SC_IW = SC_TW - 2, SC_IH = SC_TH - 2;  // candidate positions of a tile (tile step)
 constexpr int SC_FP = 72;  // LDS pitch (floats) of the staged tile (tile width + up to 3 pixels of dword alignment, rounded up to dwords)
 constexpr int SC_LP = SC_TW + 1;               // LDS pitch of the lambda block
@@ -460,8 +468,9 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // float32 although the box filter sums them in double: held as float64 the conversions drop to a third,
   // but the 8-byte LDS reads of the box stage then cost more than the conversions saved -- the LDS pipe is
   // nearly as busy as the VALU here -- and the kernel ran 1.7x slower.)
-  constexpr int RS = (CH + 2) / 3;  // rows of a covariance strip; the product planes are padded to 3 * RS rows
-  constexpr int CHP = 3 * RS;       // so that the last strip needs no row test
+  constexpr int NSTRIP = 3 * (SC_TH / 16);         // waves that walk columns 0..63 of the covariance tile
+  constexpr int RS = (CH + NSTRIP - 1) / NSTRIP;   // rows of a covariance strip; the product planes are padded to
+  constexpr int CHP = NSTRIP * RS;                 // NSTRIP * RS rows so that the last strip needs no row test
   constexpr int IMG_BYTES = IH * SC_FP * 4, COV_BYTES = 3 * CHP * CW * 4;
   constexpr int LAM_BYTES = (SC_TH * SC_LP * 4 + 15) & ~15;
   static_assert(IMG_BYTES % 16 == 0 && LAM_BYTES + SC_TH * SC_TW <= IMG_BYTES && SC_LCAP * 8 <= COV_BYTES,
@@ -500,14 +509,14 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   if (img_interior) {
     const unsigned int* Fw = reinterpret_cast<const unsigned int*>(F + (long long)gy0 * row_stride + (gx0 - sh));
     const unsigned int rsw = (unsigned int)row_stride >> 2;
-    for (int i = threadIdx.x; i < IH * NDW; i += 256) {
+    for (int i = threadIdx.x; i < IH * NDW; i += SC_NT) {
       const int y = i / NDW, xd = i - y * NDW;
       const unsigned int v = Fw[(unsigned int)y * rsw + (unsigned int)xd];
       *reinterpret_cast<float4*>(s_img + y * SC_FP + 4 * xd) =
           make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
     }
   } else {
-    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+    for (int i = threadIdx.x; i < IH * IW; i += SC_NT) {
       const int y = i / IW, x = i - y * IW;
       const int gy = reflect101(gy0 + y, h), gx = reflect101(gx0 + x, w);
       s_img[y * SC_FP + sh + x] = (float)F[(long long)gy * row_stride + gx];
@@ -522,14 +531,15 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // the two or three columns left over go to wave 3, one (column, row) per lane (spread over the 198 or 201
   // threads of a plain column-major split, the fourth wave would run the whole strip for half a dozen lanes).
   {
-    static_assert(3 * RS >= CH && (CW - 64) * CH <= 64 && CW > 64, "strip mapping of the covariance stage");
+    static_assert(NSTRIP * RS >= CH && (CW - 64) * CH <= 64 * (SC_NT / 64 - NSTRIP) && CW > 64,
+                  "strip mapping of the covariance stage");
     const int wv = threadIdx.x >> 6, ln = threadIdx.x & 63;
     int x, y0, nrows;
-    if (wv < 3) {
+    if (wv < NSTRIP) {
       x = ln, y0 = wv * RS, nrows = min(RS, CH - y0);
     } else {
-      const int c = ln / CH;
-      x = 64 + c, y0 = ln - c * CH, nrows = (ln < (CW - 64) * CH) ? 1 : 0;
+      const int idx = (wv - NSTRIP) * 64 + ln, c = idx / CH;
+      x = 64 + c, y0 = idx - c * CH, nrows = (idx < (CW - 64) * CH) ? 1 : 0;
     }
     const int cx = cx0 - HL + x;
     const bool xin = mirror ? (cx >= -HL && cx < cw + HR) : (cx >= 0 && cx < cw);
@@ -549,7 +559,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
       s_cov[1][yy * CW + x] = pxy;
       s_cov[2][yy * CW + x] = pyy;
     };
-    if (wv < 3 && mirror && !edge_rows) {
+    if (wv < NSTRIP && mirror && !edge_rows) {
       // every row of the tile lies inside the cell: straight-line code, no per-row test the compiler would
       // turn into a branch (as basic blocks per row the LDS reads of a row no longer overlap the arithmetic
       // of the one before: +12 % on the whole kernel, measured).  The last strip runs past row CH - 1: it reads
@@ -665,7 +675,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
     // a thread owns one column and four consecutive rows, forms the BS + 3 row sums they share once, and adds BS
     // of them per pixel (same additions, same order); positions outside the cell are skipped
     const int x = threadIdx.x & (SC_TW - 1), y0 = (threadIdx.x / SC_TW) * 4;
-    static_assert(SC_TH == 16 && SC_TW * 4 == 256, "strip mapping");
+    static_assert(SC_TW == 64 && SC_TH * SC_TW == SC_NT * 4, "strip mapping");
     if (cx0 + x < cw && cy0 + y0 < ch) {
       // the four mask bytes first (rows clamped into the cell), so that their global latency runs under the row
       // sums (loaded per pixel behind the row test the kernel also needs 6 to 20 registers more)
@@ -701,7 +711,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
       }
     }
   } else {
-    for (int i = threadIdx.x; i < SC_TH * SC_TW; i += 256) {
+    for (int i = threadIdx.x; i < SC_TH * SC_TW; i += SC_NT) {
       const int y = i / SC_TW, x = i - y * SC_TW;
       const int cx = cx0 + x, cy = cy0 + y;
       if (cx >= 0 && cx < cw && cy >= 0 && cy < ch) {
@@ -739,8 +749,8 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   const unsigned int lb = max(seen, blk_max);  // lower bound of the cell's final masked maximum (0: none yet)
   const float thr_lb = lb ? (float)((double)float_order_decode(lb) * quality) : -INFINITY;
 #pragma unroll
-  for (int k = 0; k < SC_TH * SC_TW / 256; k++) {
-    const int x = threadIdx.x & (SC_TW - 1), y = (threadIdx.x >> 6) + 4 * k;  // position in the lambda block
+  for (int k = 0; k < SC_TH * SC_TW / SC_NT; k++) {
+    const int x = threadIdx.x & (SC_TW - 1), y = (threadIdx.x >> 6) + (SC_NT / 64) * k;  // position in the lambda block
     const int cx = cx0 + x, cy = cy0 + y;
     if (x >= 1 && x <= SC_TW - 2 && y >= 1 && y <= SC_TH - 2 && cx >= 1 && cx < cw - 1 && cy >= 1 && cy < ch - 1) {
       const float* c = s_lam + y * SC_LP + x;
@@ -770,7 +780,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   const int nl = min(s_n, SC_LCAP);
   if (threadIdx.x == 0 && nl > 0) s_base = atomicAdd(ccnt, nl);
   __syncthreads();
-  for (int i = threadIdx.x; i < nl; i += 256) {
+  for (int i = threadIdx.x; i < nl; i += SC_NT) {
     const int slot = s_base + i;
     if (slot < cand_cap) cand[slot] = s_keys[i];
   }
@@ -781,8 +791,11 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
 // with one returning atomic on its cell's counter, and with the tiles of ONE cell in flight together a few hundred
 // blocks queue on one address (the L2's same-address atomic rate: 1.67 against 1.30 ms per 1024 frames, measured on
 // the former separate candidates kernel).
+#ifndef VSF_SC_W4
+#define VSF_SC_W4 7  // waves per SIMD the 4x4-box instance is compiled for (at 8 it spills)
+#endif
 template <int BS, bool HARRIS = false>
-__global__ __launch_bounds__(256, (BS == 4 ? 7 : 8)) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
+__global__ __launch_bounds__(SC_NT, (BS == 4 ? VSF_SC_W4 : 8)) void score_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
                                                     int row_stride, int w, int h,
                                                     const uint8_t* __restrict__ masks, long long mask_sstride,
                                                     int mask_row_stride, GridView G,
@@ -812,7 +825,7 @@ __global__ __launch_bounds__(256, (BS == 4 ? 7 : 8)) void score_kernel(const uin
 // max * quality, quality in [0, 1], is then at or above the maximum, so no response passes it; the candidate list
 // holds positive local maxima only and is empty as well.)
 template <int BS, bool HARRIS = false>
-__global__ __launch_bounds__(256) void lam_fill_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
+__global__ __launch_bounds__(SC_NT) void lam_fill_kernel(const uint8_t* __restrict__ frames, long long frame_sstride,
                                                        int row_stride, int w, int h,
                                                        const uint8_t* __restrict__ masks, long long mask_sstride,
                                                        int mask_row_stride, GridView G,
