@@ -274,3 +274,38 @@ def test_detector_tile_geometry(vsf, oracle, w, h, rows, cols):
     assert n == T.n.value
     assert np.array_equal(ids[:n], T.ids[:n]) and np.array_equal(xy[:n], T.xy[:n]) and np.array_equal(age[:n], T.age[:n])
     ctx.close()
+
+
+@pytest.mark.parametrize("anms", [False, True])
+def test_lambda_map_of_low_contrast_images(vsf, oracle, anms):
+    """The smaller eigenvalue needs a correctly rounded square root; the kernel takes v_sqrt_f32 plus two residual
+    tests and sends arguments under 2^-96 (where the residuals underflow) to sqrtf.  Images whose gradients are a
+    grey level or two -- a - c of the order of one ulp, b = 0 -- put the argument in and around that range."""
+    w, h = 192, 64
+    rng = np.random.default_rng(17)
+    imgs = []
+    img = np.full((h, w), 100, np.uint8)
+    img[rng.random((h, w)) < 0.03] += 1          # isolated single-level steps
+    imgs.append(img)
+    img = np.full((h, w), 7, np.uint8)
+    img[:, ::2] += 1                              # one-level stripes: b = 0, a != c
+    img[20:40, 50:90] += rng.integers(0, 2, (20, 40)).astype(np.uint8)
+    imgs.append(img)
+    ramp = (np.arange(w)[None, :] // 16 + np.arange(h)[:, None] // 16).astype(np.uint8)
+    imgs.append(ramp)                             # one-level steps every 16 pixels, crossing
+    bs = 4 if anms else 3
+    kw = dict(detector_kind=vsf.DETECTOR_ANMS, anms_ignore_edge=0) if anms else {}
+    ctx = vsf.Context(vsf.default_params(width=w, height=h, grid_rows=1, grid_cols=1, max_features=40, min_distance=3.0,
+                                         klt_win=3, klt_max_level=0, **kw))
+    det = oracle.AnmsDetector(40, 3.0, detection_ignore_edge=0) if anms else oracle.Detector(1, 1, 40, 3.0)
+    for img in imgs:
+        ref = oracle.corner_min_eigen_val(img, block_size=bs)
+        if not anms:
+            got, _ = ctx.debug_min_eig(img, 0)
+            assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+        ids, xy, age = _table(ctx.capacity)
+        n = ctx.detect(img, ids, xy, age, 0)
+        T = oracle.FeatureTable(ctx.capacity)   # (the id counter runs on across the images, in both)
+        det.update_detection(T, img)
+        assert n == T.n.value and np.array_equal(xy[:n], T.xy[:n]) and np.array_equal(ids[:n], T.ids[:n])
+    ctx.close()

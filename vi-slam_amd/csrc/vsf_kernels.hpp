@@ -407,6 +407,19 @@ __device__ __forceinline__ float float_order_decode(unsigned int e) {
   return __uint_as_float((e & 0x80000000u) ? (e & 0x7fffffffu) : ~e);
 }
 
+// Correctly rounded square root of a finite x >= 0: v_sqrt_f32 (1 ulp) and the two residual tests the compiler's
+// own lowering of sqrtf ends with, without its range scaling (eight more instructions per call, a quarter of the
+// box stage's vector work).  The residuals x - s * (s -+ 1 ulp) are of the order s * ulp(s) and would be lost
+// to underflow for 0 < x < 2^-96: the caller sends such an x (a wave-uniform test) to sqrtf.
+__device__ __forceinline__ float sqrt_rn_midrange(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+  const float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+  float r = rd <= 0.f ? sd : s;
+  r = ru > 0.f ? su : r;
+  return r;
+}
+
 // Min-eigenvalue score of one grid cell tile (cv::cornerMinEigenVal on the cell ROI of the parent image;
 // SURVEY A.1 steps 1-4), the masked per-cell maximum, AND the candidate corners of the tile (steps 5-6), in one
 // pass over the frame: the lambda map is never written to memory.
@@ -629,7 +642,12 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
     return !M || M[(long long)(rc.y + cy) * mask_row_stride + (rc.x + cx)];
   };
   // lam_p / msk_p: the lambda-block / mask slot the value goes to (strip threads pass a base + constant offset)
-  auto finish = [&](int x, int y, const double (&sum)[3], bool mk, float* lam_p, uint8_t* msk_p) {
+  // (valid: the position lies inside the cell.  The strip code of the box stage finishes all four rows of a thread
+  // without a row test -- a row below the cell costs nothing extra in a wave that runs anyway, and four tests
+  // are a dozen scalar instructions of mask bookkeeping -- so an invalid row arrives here with sums of whatever the
+  // padding held: it is kept out of the maximum and of the cell's map, and what it leaves in the lambda block is
+  // never read, a candidate's neighbours being rows of the cell.)
+  auto finish = [&](int x, int y, const double (&sum)[3], bool mk, bool valid, float* lam_p, uint8_t* msk_p) {
     const int cx = cx0 + x, cy = cy0 + y;
     if (HARRIS) {
       // cv's calcHarris: groups of four pixels of a row in float32 with (float)k, products left to right; the last
@@ -642,12 +660,12 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
         lm = ac_bb - (float)harris_k * t * t;
       else
         lm = (float)((double)ac_bb - harris_k * (double)t * (double)t);
-      if (WRITE_LAM) lam_cell[cy * cw + cx] = lm;
+      if (WRITE_LAM && valid) lam_cell[cy * cw + cx] = lm;
       if (EMIT) {
         *lam_p = lm;
         *msk_p = mk ? 1 : 0;
       }
-      local_maxf = fmaxf(local_maxf, mk ? lm : -INFINITY);
+      local_maxf = fmaxf(local_maxf, (mk && valid) ? lm : -INFINITY);
       return;
     }
     const float a = (float)sum[0] * 0.5f, b = (float)sum[1], c = (float)sum[2] * 0.5f;
@@ -657,8 +675,18 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
     // instructions) is skipped -- for whole waves in smooth regions.
     float lm = 0.f;
     const bool full = WRITE_LAM || a + c > thr_seen;
-    if (full) lm = (a + c) - sqrtf((a - c) * (a - c) + b * b);
-    if (WRITE_LAM) lam_cell[cy * cw + cx] = lm;
+    if (full) {
+      const float q = (a - c) * (a - c) + b * b;
+      float sq;
+      if (__ballot(q < 0x1p-96f && q != 0.f) == 0ull) {
+        sq = sqrt_rn_midrange(q);
+      } else {
+        asm volatile("");  // (rare: a block of its own)
+        sq = sqrtf(q);
+      }
+      lm = (a + c) - sq;
+    }
+    if (WRITE_LAM && valid) lam_cell[cy * cw + cx] = lm;
     if (EMIT) {
       *lam_p = lm;
       *msk_p = mk ? 1 : 0;
@@ -666,7 +694,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
     // (a skipped pixel's stand-in 0 may join the maximum: it is skipped only below a threshold seen >= 0, and a
     // block maximum at or below the one seen changes nothing.)  Plain v_max_f32: fmaxf would first quiet both
     // operands, and neither can be a NaN.
-    float cand_v = mk ? lm : -INFINITY;
+    float cand_v = (mk && valid) ? lm : -INFINITY;
     asm("v_max_f32 %0, %0, %1" : "+v"(local_maxf) : "v"(cand_v));
   };
   // Box filter in double like cv::boxFilter for 32F input: row sum left to right, then the column of
@@ -707,7 +735,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
 #pragma unroll
           for (int j = 1; j < BS; j++) sum[q] += rs[q][o + j];
         }
-        if (cy0 + y0 + o < ch) finish(x, y0 + o, sum, mk4[o], lam_base + o * SC_LP, msk_base + o * SC_TW);
+        finish(x, y0 + o, sum, mk4[o], cy0 + y0 + o < ch, lam_base + o * SC_LP, msk_base + o * SC_TW);
       }
     }
   } else {
@@ -731,7 +759,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
             sum[q] = (j == 0) ? t : sum[q] + t;
           }
         }
-        finish(x, y, sum, mask_at(cx, cy), s_lam + y * SC_LP + x, s_msk + y * SC_TW + x);
+        finish(x, y, sum, mask_at(cx, cy), true, s_lam + y * SC_LP + x, s_msk + y * SC_TW + x);
       }
     }
   }
