@@ -525,9 +525,16 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
     // (cell-major on purpose: with the ANMS detector's stream-major order -- the tiles of a cell spread in time, so
     // that later tiles start with the cell maximum the earlier ones found and skip more square roots -- the kernel
     // took 1.43 instead of 1.26 ms per 1024 frames at C2: the tiles of 1024 frames in flight together miss the L2)
-    hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x * tiles_y * c->ncell, streams), dim3(SC_NT), 0, s, f.ptr, f.sstride,
-                       f.pitch, W, H, masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, tiles_y, c->k_side,
-                       c->k_mid, c->p.quality_level, c->d_cellmax, c->d_cand, c->cand_cap, c->d_candcnt, 0, 0.0);
+    // blockIdx.z = (stream - stream0) * cells + cell: at most 65535 of them a launch
+    const unsigned int cell_magic = (unsigned int)((0x100000000ull + (unsigned)c->ncell - 1) / (unsigned)c->ncell);
+    const int per_launch = 65535 / c->ncell;
+    for (int s0 = 0; s0 < streams; s0 += per_launch) {
+      const int ns = streams - s0 < per_launch ? streams - s0 : per_launch;
+      hipLaunchKernelGGL(score_kernel<3>, dim3(tiles_x, tiles_y, ns * c->ncell), dim3(SC_NT), 0, s, f.ptr, f.sstride,
+                         f.pitch, W, H, masks, mask_sstride, mask_pitch, G, c->d_nact, tiles_x, tiles_y, c->k_side,
+                         c->k_mid, c->p.quality_level, c->d_cellmax, c->d_cand, c->cand_cap, c->d_candcnt, 0, 0.0, s0,
+                         cell_magic);
+    }
   }
   {  // cells whose candidate list overflowed (rare): their lambda map, for select_kernel's exact fallback
     ProfScope prof(c, VSF_K_CANDIDATES, s);
@@ -589,9 +596,9 @@ int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long l
   {
     ProfScope prof(c, VSF_K_SCORE, s);
     auto launch = [&](auto kern) {
-      hipLaunchKernelGGL(kern, dim3(streams, tiles_x * tiles_y), dim3(SC_NT), 0, s, f.ptr, f.sstride, f.pitch, W, H,
+      hipLaunchKernelGGL(kern, dim3(streams, tiles_x, tiles_y), dim3(SC_NT), 0, s, f.ptr, f.sstride, f.pitch, W, H,
                          c->d_aflag, fsz, W, G, c->d_anact, tiles_x, tiles_y, c->ak_side, c->ak_mid, ap.quality,
-                         c->d_cellmax, c->d_acand, ap.cand_cap, c->d_candcnt, 1, c->p.anms_harris_k);
+                         c->d_cellmax, c->d_acand, ap.cand_cap, c->d_candcnt, 1, c->p.anms_harris_k, 0, 0u);
     };
     const bool b4 = c->p.anms_block_size == 4, hr = c->p.anms_use_harris != 0;
     if (b4 && !hr) launch(score_kernel<4, false>);
@@ -928,6 +935,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   // the LK window must fit the frame; an LSSD context never runs the LK kernels
   if (p->tracker_kind != VSF_TRACKER_LSSD && (p->width <= p->klt_win || p->height <= p->klt_win)) return VSF_E_INVALID;
   if (p->grid_rows < 1 || p->grid_cols < 1 || p->max_features < 0 || p->block_size != 3) return VSF_E_INVALID;
+  if ((long long)p->grid_rows * p->grid_cols > 65535) return VSF_E_INVALID;  // a cell index travels in blockIdx.z
   // quality in [0, 1]: cv accepts more, but a threshold above the maximum keeps nothing, and the fused score kernel's
   // "local maximum first, threshold later" is equivalent to cv's order only in this range (vsf_kernels.hpp)
   if (!(p->min_distance >= 0.0) || !(p->quality_level >= 0.0) || p->quality_level > 1.0) return VSF_E_INVALID;

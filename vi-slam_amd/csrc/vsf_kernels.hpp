@@ -507,7 +507,6 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // block-uniform: this tile holds a mirrored row (only the cell's first and last tile rows do)
   const bool edge_rows = cy0 == 0 || ch - cy0 < SC_TH + HR + 1;
   unsigned int seen = 0u;
-  if (EMIT) seen = __hip_atomic_load(cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) {
     s_max = 0u;
     s_n = 0;
@@ -522,13 +521,30 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   if (img_interior) {
     const unsigned int* Fw = reinterpret_cast<const unsigned int*>(F + (long long)gy0 * row_stride + (gx0 - sh));
     const unsigned int rsw = (unsigned int)row_stride >> 2;
-    for (int i = threadIdx.x; i < IH * NDW; i += SC_NT) {
-      const int y = i / NDW, xd = i - y * NDW;
-      const unsigned int v = Fw[(unsigned int)y * rsw + (unsigned int)xd];
-      *reinterpret_cast<float4*>(s_img + y * SC_FP + 4 * xd) =
-          make_float4((float)(v & 255u), (float)((v >> 8) & 255u), (float)((v >> 16) & 255u), (float)(v >> 24));
+    // every load of the thread is in flight (and the cell maximum seen so far behind them) before the first
+    // conversion waits: a block spends its first microseconds on latency, during which its LDS keeps another from
+    // the CU
+    constexpr int NLD = (IH * NDW + SC_NT - 1) / SC_NT;
+    unsigned int v[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      // (lanes past the end load the last dword again: no branch between the loads)
+      const int i = min((int)threadIdx.x + k * SC_NT, IH * NDW - 1), y = i / NDW, xd = i - y * NDW;
+      v[k] = Fw[(unsigned int)y * rsw + (unsigned int)xd];
     }
+    unsigned int seen_v = 0u;
+    if (EMIT) seen_v = __hip_atomic_load(cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+      const int i = (int)threadIdx.x + k * SC_NT, y = i / NDW, xd = i - y * NDW;
+      if (i < IH * NDW)
+        *reinterpret_cast<float4*>(s_img + y * SC_FP + 4 * xd) = make_float4(
+            (float)(v[k] & 255u), (float)((v[k] >> 8) & 255u), (float)((v[k] >> 16) & 255u), (float)(v[k] >> 24));
+    }
+    asm volatile("" : "+v"(seen_v));  // (stays a vector value until here: no wait for it in front of the conversions)
+    seen = (unsigned int)__builtin_amdgcn_readfirstlane((int)seen_v);
   } else {
+    if (EMIT) seen = __hip_atomic_load(cmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int i = threadIdx.x; i < IH * IW; i += SC_NT) {
       const int y = i / IW, x = i - y * IW;
       const int gy = reflect101(gy0 + y, h), gx = reflect101(gx0 + x, w);
@@ -814,11 +830,15 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   }
 }
 
-// Fused score + candidates.  Grid: (tiles * cells, streams), or with stream_major (streams, tiles * cells): the ANMS
-// detector's single whole-frame cell, where the blocks in flight should belong to many streams -- every block ends
-// with one returning atomic on its cell's counter, and with the tiles of ONE cell in flight together a few hundred
-// blocks queue on one address (the L2's same-address atomic rate: 1.67 against 1.30 ms per 1024 frames, measured on
-// the former separate candidates kernel).
+// Fused score + candidates.  Grid: (tiles_x, tiles_y, streams * cells) -- blockIdx.z = (stream - stream0) * cells +
+// cell; the host splits the streams over several launches when that exceeds the grid's 65535 -- or with
+// stream_major (streams, tiles_x, tiles_y): the ANMS detector's single whole-frame cell, where the blocks in
+// flight should belong to many streams -- every block ends with one returning atomic on its cell's counter, and
+// with the tiles of ONE cell in flight together a few hundred blocks queue on one address (the L2's same-address
+// atomic rate: 1.67 against 1.30 ms per 1024 frames, measured on the former separate candidates kernel).
+// The block's coordinates come from the three grid indices and ONE multiply-high (cell_magic = ceil(2^32 / cells),
+// exact for blockIdx.z * cells < 2^32): decoded from a flat index they took two integer divisions, some fifty scalar
+// instructions in front of every wave -- a tenth of the kernel's issue slots at four waves a block.
 #ifndef VSF_SC_W4
 #define VSF_SC_W4 7  // waves per SIMD the 4x4-box instance is compiled for (at 8 it spills)
 #endif
@@ -832,17 +852,29 @@ __global__ __launch_bounds__(SC_NT, (BS == 4 ? VSF_SC_W4 : 8)) void score_kernel
                                                     unsigned int* __restrict__ cell_max,
                                                     unsigned long long* __restrict__ cand, int cand_cap,
                                                     int* __restrict__ cand_cnt, int stream_major,
-                                                    double harris_k) {
-  const int stream = stream_major ? blockIdx.x : blockIdx.y;
-  const int tc = stream_major ? blockIdx.y : blockIdx.x;
-  const int tpc = tiles_x * tiles_y;
-  const int cell = tc / tpc, tile = tc - cell * tpc;
-  if (cell >= n_active[stream]) return;
+                                                    double harris_k, int stream0, unsigned int cell_magic) {
+  // every argument in a scalar register NOW: one batch of wide scalar loads and one wait, where the compiler would
+  // fetch them a few at a time as the code reaches them, a memory round trip each
+  asm volatile("" ::"s"(frames), "s"(frame_sstride), "s"(row_stride), "s"(w), "s"(h), "s"(masks), "s"(mask_sstride),
+               "s"(mask_row_stride), "s"(G.rects), "s"(G.ncell), "s"(n_active), "s"(k_side), "s"(k_mid), "s"(quality),
+               "s"(cell_max), "s"(cand), "s"(cand_cap), "s"(cand_cnt), "s"(stream_major), "s"(stream0), "s"(cell_magic));
+  int stream, cell, tx, ty;
+  if (stream_major) {
+    stream = blockIdx.x, cell = 0, tx = blockIdx.y, ty = blockIdx.z;
+  } else {
+    const int ds = (int)__umulhi(blockIdx.z, cell_magic);
+    stream = stream0 + ds, cell = (int)blockIdx.z - ds * G.ncell, tx = blockIdx.x, ty = blockIdx.y;
+  }
+  // (read through the constant address space: scalar loads whatever the compiler can prove about the asm above;
+  // both arrays were written by kernels that ended before this one started)
+  typedef const int __attribute__((address_space(4))) * const_int_p;
+  if (cell >= ((const_int_p)(uintptr_t)n_active)[stream]) return;
+  const const_int_p rp = (const_int_p)(uintptr_t)(G.rects + cell);
+  const int4 rect = make_int4(rp[0], rp[1], rp[2], rp[3]);
   const int sc = stream * G.ncell + cell;
-  const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
   score_tile<BS, false, true, HARRIS>(frames + (long long)stream * frame_sstride, row_stride, w, h,
                                       masks ? masks + (long long)stream * mask_sstride : nullptr, mask_row_stride,
-                                      G.rects[cell], tx, ty, k_side, k_mid, nullptr, cell_max + sc, quality,
+                                      rect, tx, ty, k_side, k_mid, nullptr, cell_max + sc, quality,
                                       cand + (long long)sc * cand_cap, cand_cap, cand_cnt + sc, harris_k);
 }
 
