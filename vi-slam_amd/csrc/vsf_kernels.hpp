@@ -792,22 +792,42 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
   // ---- candidates of the inner 62 x 14 positions
   const unsigned int lb = max(seen, blk_max);  // lower bound of the cell's final masked maximum (0: none yet)
   const float thr_lb = lb ? (float)((double)float_order_decode(lb) * quality) : -INFINITY;
+  // A thread looks at the four rows of one column it finished in the box stage.  The four values and mask bytes
+  // are read together and tested together -- a candidate is rare, most waves leave here --; the 3 x 3 maxima of
+  // the four rows share their six row maxima.  (Row and column indices that fall off the block are clamped or read
+  // the pad column: they only feed positions on the block's rim, which are no candidates of this tile.)
+  {
+    const int x = threadIdx.x & (SC_TW - 1), y0 = (int)(threadIdx.x >> 6) * 4, cx = cx0 + x;
+    const float* col = s_lam + x;
+    float vc[4];
+    uint8_t mc[4];
 #pragma unroll
-  for (int k = 0; k < SC_TH * SC_TW / SC_NT; k++) {
-    const int x = threadIdx.x & (SC_TW - 1), y = (threadIdx.x >> 6) + (SC_NT / 64) * k;  // position in the lambda block
-    const int cx = cx0 + x, cy = cy0 + y;
-    if (x >= 1 && x <= SC_TW - 2 && y >= 1 && y <= SC_TH - 2 && cx >= 1 && cx < cw - 1 && cy >= 1 && cy < ch - 1) {
-      const float* c = s_lam + y * SC_LP + x;
-      const float v = c[0];
-      if (v > 0.f && v > thr_lb && s_msk[y * SC_TW + x]) {
-        float m = v;
+    for (int o = 0; o < 4; o++) {
+      vc[o] = col[(y0 + o) * SC_LP];
+      mc[o] = s_msk[(y0 + o) * SC_TW + x];
+    }
+    const bool xok = x >= 1 && x <= SC_TW - 2 && cx >= 1 && cx < cw - 1;
+    bool pass[4], any = false;
 #pragma unroll
-        for (int j = -1; j <= 1; j++)
+    for (int o = 0; o < 4; o++) {
+      const int y = y0 + o, cy = cy0 + y;
+      pass[o] = xok && y >= 1 && y <= SC_TH - 2 && cy >= 1 && cy < ch - 1 && vc[o] > 0.f && vc[o] > thr_lb && mc[o] != 0;
+      any |= pass[o];
+    }
+    if (any) {
+      float hm[6];
 #pragma unroll
-          for (int q = -1; q <= 1; q++) m = fmaxf(m, c[j * SC_LP + q]);
-        if (v == m) {
+      for (int r = 0; r < 6; r++) {
+        const int yy = min(max(y0 - 1 + r, 0), SC_TH - 1);
+        const float* c = col + yy * SC_LP;
+        hm[r] = fmaxf(fmaxf(c[-1], c[0]), c[1]);
+      }
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        if (pass[o] && vc[o] == fmaxf(fmaxf(hm[o], hm[o + 1]), hm[o + 2])) {
           // key = lambda bits << 32 | raster index: unsigned order = cv's greaterThanPtr order (value, then address)
-          const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)(cy * cw + cx);
+          const unsigned long long key =
+              ((unsigned long long)__float_as_uint(vc[o]) << 32) | (unsigned int)((cy0 + y0 + o) * cw + cx);
           const int ls = atomicAdd(&s_n, 1);
           if (ls < SC_LCAP) {
             s_keys[ls] = key;
@@ -868,9 +888,11 @@ __global__ __launch_bounds__(SC_NT, (BS == 4 ? VSF_SC_W4 : 8)) void score_kernel
   // (read through the constant address space: scalar loads whatever the compiler can prove about the asm above;
   // both arrays were written by kernels that ended before this one started)
   typedef const int __attribute__((address_space(4))) * const_int_p;
-  if (cell >= ((const_int_p)(uintptr_t)n_active)[stream]) return;
+  const int nact = ((const_int_p)(uintptr_t)n_active)[stream];
   const const_int_p rp = (const_int_p)(uintptr_t)(G.rects + cell);
   const int4 rect = make_int4(rp[0], rp[1], rp[2], rp[3]);
+  asm volatile("" ::"s"(nact), "s"(rect.x), "s"(rect.y), "s"(rect.z), "s"(rect.w));  // (both loads, then one wait)
+  if (cell >= nact) return;
   const int sc = stream * G.ncell + cell;
   score_tile<BS, false, true, HARRIS>(frames + (long long)stream * frame_sstride, row_stride, w, h,
                                       masks ? masks + (long long)stream * mask_sstride : nullptr, mask_row_stride,
