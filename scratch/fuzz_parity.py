@@ -48,9 +48,22 @@ while time.time() < t_end:
             P.detection_feature_number_ = 2 * maxn; P.detection_ignore_edge_ = int(rng.choice([0, 5, 20]))
             if w <= 2 * P.detection_ignore_edge_ + 8 or h <= 2 * P.detection_ignore_edge_ + 8:
                 continue
+            # the rest of the Parameter (round 3): Harris response, cv's minDistance above 1, block size, quality
+            P.detection_use_harris_corner_ = bool(rng.random() < 0.35)
+            P.detection_k_ = float(rng.choice([0.04, 0.06, 0.15]))
+            P.detection_min_feature_distance_ = float(rng.choice([1.0, 1.0, 0.0, 1.3, 2.0, 4.5, 9.0, 31.0]))
+            P.detection_block_size_ = int(rng.choice([3, 4, 4]))
+            P.detection_quality_level_ = float(rng.choice([0.001, 0.001, 0.05, 0.0]))
+            desc["anms"] = (P.detection_use_harris_corner_, P.detection_k_, P.detection_min_feature_distance_,
+                            P.detection_block_size_, P.detection_quality_level_, P.detection_ignore_edge_)
             det = vsf.FeatureDetectorANMS(P, w, h, capacity=cap)
             odet = O.AnmsDetector(maxn, mind, detection_feature_number=2 * maxn,
-                                  detection_ignore_edge=P.detection_ignore_edge_)
+                                  detection_ignore_edge=P.detection_ignore_edge_,
+                                  detection_use_harris_corner=int(P.detection_use_harris_corner_),
+                                  detection_k=P.detection_k_,
+                                  detection_min_feature_distance=P.detection_min_feature_distance_,
+                                  detection_block_size=P.detection_block_size_,
+                                  detection_quality_level=P.detection_quality_level_)
         else:
             det = vsf.FeatureDetectorShiTomasiBucketing(rows, cols, maxn, mind, w, h, capacity=cap)
             odet = O.Detector(rows, cols, maxn, mind)

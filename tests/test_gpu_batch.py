@@ -97,6 +97,28 @@ def test_batch_step_matches_per_stream_oracle(vsf, oracle, synth):
     ctx.close()
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 1), (1, 2), (3, 1), (5, 7)])
+def test_batch_step_grids_of_few_and_many_cells(vsf, oracle, synth, rows, cols):
+    """The score kernel finds (stream, cell) from blockIdx.z through a reciprocal of the cell count: a single cell
+    (whose reciprocal does not fit 32 bits), two, an odd count, and more cells than streams."""
+    import torch
+    w, h, B, T = 200, 150, 7, 3
+    frames = np.stack([synth.sequence(900 + b, w, h, T)[0] for b in range(B)], 1)
+    maxn = 12 * rows * cols
+    p = vsf.default_params(grid_rows=rows, grid_cols=cols, max_features=maxn, min_distance=4.0, klt_win=15,
+                           klt_max_level=2, width=w, height=h, streams=B, capacity=maxn + 64)
+    ctx = vsf.Context(p)
+    dev = torch.from_numpy(frames).cuda()
+    exp, _ = _oracle_streams(oracle, frames, (rows, cols, maxn, 4.0), (30, 0.01, 15, 2, 1.0), maxn + 64)
+    for t in range(T):
+        ctx.batch_step(dev[t].data_ptr(), h * w, w, torch.cuda.current_stream().cuda_stream)
+        ids, xy, age, n, _ = ctx.batch_download()
+        for b in range(B):
+            got = {int(i): (float(q[0]), float(q[1]), int(a)) for i, q, a in zip(ids[b, :n[b]], xy[b, :n[b]], age[b, :n[b]])}
+            assert got == exp[t][b] and len(got) > 5, "step %d stream %d" % (t, b)
+    ctx.close()
+
+
 def test_batch_detect_with_masks_and_upload(vsf, oracle, synth):
     import torch
     w, h, B = 240, 160, 3

@@ -526,7 +526,8 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
     // that later tiles start with the cell maximum the earlier ones found and skip more square roots -- the kernel
     // took 1.43 instead of 1.26 ms per 1024 frames at C2: the tiles of 1024 frames in flight together miss the L2)
     // blockIdx.z = (stream - stream0) * cells + cell: at most 65535 of them a launch
-    const unsigned int cell_magic = (unsigned int)((0x100000000ull + (unsigned)c->ncell - 1) / (unsigned)c->ncell);
+    const unsigned int cell_magic =
+        c->ncell == 1 ? 0u : (unsigned int)((0x100000000ull + (unsigned)c->ncell - 1) / (unsigned)c->ncell);
     const int per_launch = 65535 / c->ncell;
     for (int s0 = 0; s0 < streams; s0 += per_launch) {
       const int ns = streams - s0 < per_launch ? streams - s0 : per_launch;

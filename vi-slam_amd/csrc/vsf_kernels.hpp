@@ -857,7 +857,7 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
 // with the tiles of ONE cell in flight together a few hundred blocks queue on one address (the L2's same-address
 // atomic rate: 1.67 against 1.30 ms per 1024 frames, measured on the former separate candidates kernel).
 // The block's coordinates come from the three grid indices and ONE multiply-high (cell_magic = ceil(2^32 / cells),
-// exact for blockIdx.z * cells < 2^32): decoded from a flat index they took two integer divisions, some fifty scalar
+// exact for blockIdx.z * cells < 2^32; 0 stands for a single cell, whose reciprocal does not fit 32 bits): decoded from a flat index they took two integer divisions, some fifty scalar
 // instructions in front of every wave -- a tenth of the kernel's issue slots at four waves a block.
 #ifndef VSF_SC_W4
 #define VSF_SC_W4 7  // waves per SIMD the 4x4-box instance is compiled for (at 8 it spills)
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(SC_NT, (BS == 4 ? VSF_SC_W4 : 8)) void score_kernel
   if (stream_major) {
     stream = blockIdx.x, cell = 0, tx = blockIdx.y, ty = blockIdx.z;
   } else {
-    const int ds = (int)__umulhi(blockIdx.z, cell_magic);
+    const int ds = cell_magic ? (int)__umulhi(blockIdx.z, cell_magic) : (int)blockIdx.z;  // (0: one cell a stream)
     stream = stream0 + ds, cell = (int)blockIdx.z - ds * G.ncell, tx = blockIdx.x, ty = blockIdx.y;
   }
   // (read through the constant address space: scalar loads whatever the compiler can prove about the asm above;
