@@ -119,6 +119,29 @@ def test_batch_step_grids_of_few_and_many_cells(vsf, oracle, synth, rows, cols):
     ctx.close()
 
 
+def test_batch_of_more_stream_cells_than_one_grid_holds(vsf, oracle, synth):
+    """streams x cells above 65535 (blockIdx.z's range): the score kernel is launched once per 65535 / cells
+    streams.  4200 streams of 16 cells, replicas of three sequences; the streams around the split are checked."""
+    import torch
+    w, h, B, T, U = 96, 64, 4200, 2, 3
+    seqs = np.stack([synth.sequence(950 + u, w, h, T)[0] for u in range(U)], 1)    # [T][U][h][w]
+    p = vsf.default_params(grid_rows=4, grid_cols=4, max_features=48, min_distance=3.0, klt_win=9, klt_max_level=1,
+                           width=w, height=h, streams=B, capacity=80, lk_cache_max_bytes=-1)
+    ctx = vsf.Context(p)
+    exp, _ = _oracle_streams(oracle, seqs, (4, 4, 48, 3.0), (30, 0.01, 9, 1, 1.0), 80)
+    idx = torch.arange(B) % U
+    for t in range(T):
+        dev = torch.from_numpy(seqs[t]).cuda()[idx.cuda()].contiguous()
+        ctx.batch_step(dev.data_ptr(), h * w, w, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        ids, xy, age, n, _ = ctx.batch_download()
+        for b in (0, 1, 2, 4093, 4094, 4095, 4096, 4097, 4199):
+            got = {int(i): (float(q[0]), float(q[1]), int(a)) for i, q, a in zip(ids[b, :n[b]], xy[b, :n[b]], age[b, :n[b]])}
+            assert got == exp[t][b % U] and len(got) > 8, "step %d stream %d" % (t, b)
+        assert all(n[b] == n[b % U] for b in range(B))
+    ctx.close()
+
+
 def test_batch_detect_with_masks_and_upload(vsf, oracle, synth):
     import torch
     w, h, B = 240, 160, 3
