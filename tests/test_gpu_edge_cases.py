@@ -309,3 +309,24 @@ def test_lambda_map_of_low_contrast_images(vsf, oracle, anms):
         det.update_detection(T, img)
         assert n == T.n.value and np.array_equal(xy[:n], T.xy[:n]) and np.array_equal(ids[:n], T.ids[:n])
     ctx.close()
+
+
+def test_select_with_more_survivors_than_lds_keys(vsf, oracle):
+    """select_kernel keeps 1024 candidate keys in LDS; a noisy cell leaves more above the threshold, and the greedy
+    selection then runs on the cell's global list (keys under the threshold zeroed in place).  Also with the list
+    itself overflowing (the lambda-map path) right after, on the same context."""
+    w, h = 400, 300
+    rng = np.random.default_rng(23)
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    lam = oracle.corner_min_eigen_val(img)
+    inner = lam[1:-1, 1:-1]
+    assert (inner > 0.1 * lam.max()).sum() > 4000   # plenty above the threshold; a ninth or so are local maxima
+    for rows, cols, md in ((1, 1, 2.0), (1, 2, 6.5)):
+        ctx = vsf.Context(vsf.default_params(width=w, height=h, grid_rows=rows, grid_cols=cols, max_features=600,
+                                             min_distance=md, klt_win=9, klt_max_level=1))
+        det, T = oracle.Detector(rows, cols, 600, md), oracle.FeatureTable(ctx.capacity)
+        ids, xy, age = _table(ctx.capacity)
+        n = ctx.detect(img, ids, xy, age, 0)
+        det.update_detection(T, img)
+        assert n == T.n.value > 300 and np.array_equal(xy[:n], T.xy[:n]) and np.array_equal(ids[:n], T.ids[:n])
+        ctx.close()

@@ -507,6 +507,11 @@ int track_impl(vsf_ctx* c, const FrameRef& f, int streams, hipStream_t s) {
 int detect_anms_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long mask_sstride, int mask_pitch,
                      int streams, hipStream_t s);
 
+// candidate keys select_kernel keeps in LDS (more survivors of a cell stay in its global list)
+#ifndef VSF_SEL_LDS_KEYS
+#define VSF_SEL_LDS_KEYS 1024
+#endif
+
 int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long mask_sstride, int mask_pitch,
                 int streams, hipStream_t s) {
   if (c->p.detector_kind == VSF_DETECTOR_ANMS) return detect_anms_impl(c, f, masks, mask_sstride, mask_pitch, streams, s);
@@ -551,7 +556,8 @@ int detect_impl(vsf_ctx* c, const FrameRef& f, const uint8_t* masks, long long m
     sp.cap = c->cap;
     sp.cand_cap = c->cand_cap;
     sp.sel_cap = c->grid_max > 0 ? c->grid_max : 1;
-    const size_t sm = (size_t)c->cand_cap * 8 + (size_t)sp.sel_cap * 12;
+    sp.lds_keys = c->cand_cap < VSF_SEL_LDS_KEYS ? c->cand_cap : VSF_SEL_LDS_KEYS;
+    const size_t sm = (size_t)sp.lds_keys * 8 + (size_t)sp.sel_cap * 12;
     hipLaunchKernelGGL(select_kernel, dim3(c->ncell, streams), dim3(256), sm, s, c->d_lam, G, c->d_nact, c->d_need,
                        c->d_cellmax, masks, mask_sstride, mask_pitch, c->d_cand, c->d_candcnt, sp, c->d_xy, c->d_n,
                        c->d_selxy, c->d_selcnt);
@@ -1183,7 +1189,8 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
     // dynamic LDS above the default limit needs an explicit opt-in; the attribute belongs to the kernel, not to
     // the context, so only ever raise it (an earlier, larger context still launches with its own size)
     const int occ_sm = (c->hash_size + c->ncell + 2 * (c->p.grid_cols + c->p.grid_rows)) * 4;
-    const int sel_sm = c->cand_cap * 8 + (c->grid_max > 0 ? c->grid_max : 1) * 12;
+    const int sel_sm = (c->cand_cap < VSF_SEL_LDS_KEYS ? c->cand_cap : VSF_SEL_LDS_KEYS) * 8 +
+                       (c->grid_max > 0 ? c->grid_max : 1) * 12;
     int app_sm = (c->ncell + 1 + c->ncell * (c->grid_max > 0 ? c->grid_max : 1)) * 4;
     if (use_anms && (2 + c->anms.kcap) * 4 > app_sm) app_sm = (2 + c->anms.kcap) * 4;
     acc(raise_dynamic_lds(reinterpret_cast<const void*>(occupancy_kernel), 0, occ_sm));

@@ -946,6 +946,7 @@ struct SelParams {
   int cap;           // table capacity
   int cand_cap;
   int sel_cap;       // accepted-corner slots per cell (= grid_max)
+  int lds_keys;      // candidate keys the block's LDS holds (<= cand_cap); more survivors stay in the global list
 };
 
 __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ lam, GridView G,
@@ -954,13 +955,13 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
                                                      const unsigned int* __restrict__ cell_max,
                                                      const uint8_t* __restrict__ masks, long long mask_sstride,
                                                      int mask_row_stride,
-                                                     const unsigned long long* __restrict__ cand,
+                                                     unsigned long long* __restrict__ cand,
                                                      const int* __restrict__ cand_cnt, SelParams sp,
                                                      const double2* __restrict__ xy, const int* __restrict__ n,
                                                      double2* __restrict__ sel_xy, int* __restrict__ sel_cnt) {
   extern __shared__ __align__(16) uint8_t smem[];
-  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);  // [cand_cap], 0 = dead
-  int* s_acc_x = reinterpret_cast<int*>(s_key + sp.cand_cap);               // [sel_cap]
+  unsigned long long* s_key = reinterpret_cast<unsigned long long*>(smem);  // [lds_keys], 0 = dead
+  int* s_acc_x = reinterpret_cast<int*>(s_key + sp.lds_keys);               // [sel_cap]
   int* s_acc_y = s_acc_x + sp.sel_cap;                                      // [sel_cap]
   int* s_ok = s_acc_y + sp.sel_cap;                                         // [sel_cap]
   __shared__ unsigned long long s_red[4];
@@ -984,17 +985,28 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
   // the list holds every positive local maximum the score kernel could not rule out; cv's threshold
-  // (lambda > (float)(max * quality)) is applied here, and the survivors are compacted in LDS
+  // (lambda > (float)(max * quality)) is applied here, and the survivors are compacted in LDS.  The LDS holds
+  // lds_keys of them -- a few hundred survive in a cell of any size, and LDS sized for the list's capacity (30 KB at
+  // C2) kept all but five blocks off a CU --; when more survive (in_lds false, rare) they stay where they are, in
+  // the cell's global list, with the keys under the threshold zeroed in place.
   __shared__ int s_m;
   if (threadIdx.x == 0) s_m = 0;
   __syncthreads();
+  unsigned long long* gkey = cand + (long long)sc * sp.cand_cap;
   if (!overflow)
     for (int i = threadIdx.x; i < total; i += 256) {
-      const unsigned long long k = cand[(long long)sc * sp.cand_cap + i];
-      if (__uint_as_float((unsigned int)(k >> 32)) > thr) s_key[atomicAdd(&s_m, 1)] = k;
+      const unsigned long long k = gkey[i];
+      if (__uint_as_float((unsigned int)(k >> 32)) > thr) {
+        const int slot = atomicAdd(&s_m, 1);
+        if (slot < sp.lds_keys) s_key[slot] = k;
+      }
     }
   __syncthreads();
-  const int M = overflow ? cw * ch : s_m;
+  const bool in_lds = s_m <= sp.lds_keys;
+  if (!overflow && !in_lds)
+    for (int i = threadIdx.x; i < total; i += 256)  // (a thread owns the same elements in every pass below)
+      if (!(__uint_as_float((unsigned int)(gkey[i] >> 32)) > thr)) gkey[i] = 0ull;
+  const int M = overflow ? cw * ch : (in_lds ? s_m : total);
 
   int accepted = 0;
   int lastx = -1000000, lasty = -1000000;
@@ -1004,19 +1016,25 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
     unsigned long long best = 0ull;
     if (!overflow) {
       // fast path: the suppression by the last accepted corner is folded into the scan
-      for (int i = threadIdx.x; i < M; i += 256) {
-        const unsigned long long k = s_key[i];
-        if (k) {
-          const int idx = (int)(k & 0xffffffffull);
-          const int y = idx / cw, x = idx - y * cw;
-          const float ddx = (float)x - (float)lastx, ddy = (float)y - (float)lasty;
-          const bool dead = (k == lastkey) || (use_dist && (double)(ddx * ddx + ddy * ddy) < md2);
-          if (dead)
-            s_key[i] = 0ull;
-          else if (k > best)
-            best = k;
+      auto scan = [&](auto* keys) {
+        for (int i = threadIdx.x; i < M; i += 256) {
+          const unsigned long long k = keys[i];
+          if (k) {
+            const int idx = (int)(k & 0xffffffffull);
+            const int y = idx / cw, x = idx - y * cw;
+            const float ddx = (float)x - (float)lastx, ddy = (float)y - (float)lasty;
+            const bool dead = (k == lastkey) || (use_dist && (double)(ddx * ddx + ddy * ddy) < md2);
+            if (dead)
+              keys[i] = 0ull;
+            else if (k > best)
+              best = k;
+          }
         }
-      }
+      };
+      if (in_lds)
+        scan(s_key);
+      else
+        scan(gkey);
     } else {
       // overflow path: candidates are re-derived from the lambda map; keys are unique and visited in
       // descending order, so everything >= lastkey has been decided already
