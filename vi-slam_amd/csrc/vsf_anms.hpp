@@ -111,7 +111,7 @@ __device__ __forceinline__ unsigned long long anms_key_from_map(const float* __r
   if (v != m || !M[idx]) return 0ull;
   // (v > 0: with a negative masked maximum -- Harris on an image of edges only -- cv's threshold max * quality,
   // quality in [0, 1], is at or above that maximum, and no response at or below the maximum passes it)
-  return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)idx;
+  return ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)((y << 16) | x);
 }
 
 // The nfeatures largest candidate keys of a stream, in descending order (= cv's sorted corner list cut
@@ -121,7 +121,7 @@ __device__ __forceinline__ unsigned long long anms_key_from_map(const float* __r
 // block of a stream alone with a few hundred thousand keys: C4 with 32 streams, the single-stream host API).
 //   * The first pass also counts the keys.  A pass whose selected bin holds exactly the keys still wanted ends the
 //     search: every key with that prefix belongs to the top K (the K-th lambda is nearly always unique, so the
-//     four passes over the raster-index half of the key are rarely needed).
+//     four passes over the position half of the key are rarely needed).
 //   * Keys are read four per thread and iteration (loads in flight together), and a wave adds the keys that
 //     share the bin of its first lane with ONE LDS atomic: the upper bytes of lambda are the same for most keys
 //     of a frame, and sixteen waves adding one by one to the same address queue behind each other.
@@ -172,7 +172,8 @@ __global__ __launch_bounds__(1024) void anms_topk_kernel(const float* __restrict
     }
     if (GREEDY && U != ~0ull) {
       if (k >= U) k = 0ull;
-      if (k != 0ull && !overflow && F[(unsigned int)k] == 0) k = 0ull;  // blocked by an accepted corner
+      if (k != 0ull && !overflow && F[(int)((unsigned int)k >> 16) * ap.w + (int)((unsigned int)k & 0xffffu)] == 0)
+        k = 0ull;  // blocked by an accepted corner
     }
     return k;
   };
@@ -275,9 +276,8 @@ __global__ __launch_bounds__(1024) void anms_topk_kernel(const float* __restrict
       }
     if (!GREEDY) {
       for (int i = tid; i < K; i += NT) {
-        const int idx = (int)(unsigned int)s_key[i];
-        const int y = idx / ap.w;
-        out[i] = make_short2((short)(idx - y * ap.w), (short)y);
+        const unsigned int yx = (unsigned int)s_key[i];  // y << 16 | x
+        out[i] = make_short2((short)(yx & 0xffffu), (short)(yx >> 16));
       }
       if (tid == 0) ndet[stream] = K;
       return;
@@ -293,10 +293,10 @@ __global__ __launch_bounds__(1024) void anms_topk_kernel(const float* __restrict
       bool alive = false;
       int mx = 0, my = 0;
       if (i < K) {
-        const int idx = (int)(unsigned int)s_key[i];
-        my = idx / ap.w;
-        mx = idx - my * ap.w;
-        alive = F[idx] != 0;
+        const unsigned int yx = (unsigned int)s_key[i];
+        my = (int)(yx >> 16);
+        mx = (int)(yx & 0xffffu);
+        alive = F[my * ap.w + mx] != 0;
       }
       while (accepted < ap.nfeatures) {
         const int slot = it % 3;
@@ -307,8 +307,8 @@ __global__ __launch_bounds__(1024) void anms_topk_kernel(const float* __restrict
         if (tid == 0) s_first[(it + 2) % 3] = 0x7fffffff;
         it++;
         if (first == 0x7fffffff) break;  // the window holds no alive key
-        const int pidx = (int)(unsigned int)s_key[first];
-        const int py = pidx / ap.w, px = pidx - py * ap.w;
+        const unsigned int pyx = (unsigned int)s_key[first];
+        const int py = (int)(pyx >> 16), px = (int)(pyx & 0xffffu);
         if (tid == 0) out[accepted] = make_short2((short)px, (short)py);
         accepted++;
         const float ddx = (float)mx - (float)px, ddy = (float)my - (float)py;

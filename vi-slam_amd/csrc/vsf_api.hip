@@ -937,6 +937,7 @@ int vsf_create(const vsf_params* p, vsf_ctx** out) {
   if (!p || !out) return VSF_E_INVALID;
   *out = nullptr;
   if (p->width <= 0 || p->height <= 0 || p->streams < 1 || p->streams > 65535) return VSF_E_INVALID;
+  if (p->width > 65535 || p->height > 65535) return VSF_E_INVALID;  // candidate keys carry y << 16 | x
   if (p->klt_win < 3 || p->klt_win > MAX_WIN || p->klt_max_level < 0 || p->klt_max_level >= MAXL)
     return VSF_E_INVALID;
   // the LK window must fit the frame; an LSSD context never runs the LK kernels

@@ -825,9 +825,10 @@ __device__ __forceinline__ void score_tile(const uint8_t* __restrict__ F, int ro
 #pragma unroll
       for (int o = 0; o < 4; o++) {
         if (pass[o] && vc[o] == fmaxf(fmaxf(hm[o], hm[o + 1]), hm[o + 2])) {
-          // key = lambda bits << 32 | raster index: unsigned order = cv's greaterThanPtr order (value, then address)
+          // key = lambda bits << 32 | y << 16 | x: unsigned order = cv's greaterThanPtr order (value, then address:
+          // the raster order of (y, x), kept as two fields so that no reader has to divide by the cell width)
           const unsigned long long key =
-              ((unsigned long long)__float_as_uint(vc[o]) << 32) | (unsigned int)((cy0 + y0 + o) * cw + cx);
+              ((unsigned long long)__float_as_uint(vc[o]) << 32) | (unsigned int)(((cy0 + y0 + o) << 16) | cx);
           const int ls = atomicAdd(&s_n, 1);
           if (ls < SC_LCAP) {
             s_keys[ls] = key;
@@ -1020,8 +1021,7 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
         for (int i = threadIdx.x; i < M; i += 256) {
           const unsigned long long k = keys[i];
           if (k) {
-            const int idx = (int)(k & 0xffffffffull);
-            const int y = idx / cw, x = idx - y * cw;
+            const int y = (int)((unsigned int)k >> 16), x = (int)((unsigned int)k & 0xffffu);
             const float ddx = (float)x - (float)lastx, ddy = (float)y - (float)lasty;
             const bool dead = (k == lastkey) || (use_dist && (double)(ddx * ddx + ddy * ddy) < md2);
             if (dead)
@@ -1044,7 +1044,7 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
         float v = L[i];
         v = v > thr ? v : 0.f;
         if (v == 0.f) continue;
-        const unsigned long long k = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)i;
+        const unsigned long long k = ((unsigned long long)__float_as_uint(v) << 32) | (unsigned int)((y << 16) | x);
         if (k >= lastkey || k <= best) continue;
         float m = v;
         for (int j = -1; j <= 1; j++)
@@ -1074,9 +1074,8 @@ __global__ __launch_bounds__(256) void select_kernel(const float* __restrict__ l
     best = s_red[0];
     for (int k = 1; k < 4; k++) best = s_red[k] > best ? s_red[k] : best;
     if (best == 0ull) break;
-    const int idx = (int)(best & 0xffffffffull);
-    lasty = idx / cw;
-    lastx = idx - lasty * cw;
+    lasty = (int)((unsigned int)best >> 16);
+    lastx = (int)((unsigned int)best & 0xffffu);
     lastkey = best;
     if (threadIdx.x == 0) {
       s_acc_x[accepted] = lastx;
