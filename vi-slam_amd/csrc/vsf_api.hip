@@ -346,7 +346,10 @@ int launch_lk_fb(vsf_ctx* c, const PyrView& P, const PyrView& C, int streams, hi
   // workgroups per stream: the table size a detector maintains (+ slack), not the (larger) capacity
   int fgrid = c->p.max_features + 64;
   if (fgrid > c->cap) fgrid = c->cap;
-  dim3 grid((unsigned)(8 * fgrid * ((streams + 7) / 8)));  // 8 XCD residue classes x streams x features
+  // x = 8 XCD residue classes x features, y = groups of eight streams: the linear workgroup id (x + gridDim.x * y,
+  // the order of dispatch) modulo 8 is the stream's residue class, and the kernel reads stream and feature off the two
+  // indices without a division
+  dim3 grid((unsigned)(8 * fgrid), (unsigned)((streams + 7) / 8));
 #define VSF_LAUNCH_W(SEG)                                                                                       \
   hipLaunchKernelGGL(lk_fb_kernel<SEG>, grid, dim3(64), c->lks.total, s, P, C, c->d_xy, c->d_n, c->cap, fgrid, \
                      streams, c->lk, c->d_fwd, c->d_flags, cache)
@@ -448,7 +451,7 @@ int lssd_track_impl(vsf_ctx* c, const FrameRef& f, int streams, hipStream_t s) {
       ProfScope prof(c, VSF_K_LK, s);
       int fgrid = (c->p.max_features + 64 + 1) / 2;  // feature pairs per stream
       if (fgrid > (c->cap + 1) / 2) fgrid = (c->cap + 1) / 2;
-      dim3 grid((unsigned)(8 * fgrid * ((streams + 7) / 8)));
+      dim3 grid((unsigned)(8 * fgrid), (unsigned)((streams + 7) / 8));
       const LssdState st = {c->d_lssd_ids, c->d_lssd_xy, c->d_lssd_n};
       hipLaunchKernelGGL(lssd_fb_kernel, grid, dim3(64), 0, s, P, C, c->d_ids, c->d_xy, c->d_n, c->cap, fgrid, streams,
                          c->lssd, st, c->d_fwd, c->d_flags);

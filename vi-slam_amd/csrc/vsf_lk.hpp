@@ -1270,9 +1270,9 @@ __global__ __launch_bounds__(64, (SEG <= 8 ? VSF_LK_WAVES : 2)) void lk_fb_kerne
   // fetched into a single L2 instead of eight.  Placement is a speed matter only.
   // fgrid workgroups serve a stream; feature f0 + k * fgrid goes to workgroup f0 (k > 0 only when a
   // table holds more than fgrid entries, which the usual table size never does).
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-  const int grp = local / fgrid;
-  const int stream = grp * 8 + xcd, f0 = local - grp * fgrid;
+  // (grid: x = 8 * fgrid, y = groups of eight streams; the dispatch order is x + gridDim.x * y)
+  const int xcd = blockIdx.x & 7, f0 = blockIdx.x >> 3;
+  const int stream = (int)blockIdx.y * 8 + xcd;
   if (stream >= nstreams) return;
   const int nf = n[stream];
   if (f0 >= nf) return;

@@ -423,9 +423,9 @@ __global__ __launch_bounds__(64, 6) void lssd_fb_kernel(Pyr16View P, Pyr16View C
                                                      const double2* __restrict__ xy, const int* __restrict__ n,
                                                      int cap, int fgrid, int nstreams, LssdParams prm, LssdState st,
                                                      float2* __restrict__ fwd, uint8_t* __restrict__ flags) {
-  const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;  // same XCD-aware map as lk_fb_kernel
-  const int grp = local / fgrid;
-  const int stream = grp * 8 + xcd, pair0 = local - grp * fgrid;
+  // same XCD-aware map as lk_fb_kernel: grid x = 8 * fgrid, y = groups of eight streams
+  const int xcd = blockIdx.x & 7, pair0 = blockIdx.x >> 3;
+  const int stream = (int)blockIdx.y * 8 + xcd;
   if (stream >= nstreams) return;
   const int nf = n[stream];
   const int half = (threadIdx.x >> 5) & 1, sub = threadIdx.x & 31;
