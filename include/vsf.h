@@ -43,7 +43,7 @@ typedef struct vsf_ctx vsf_ctx;
  * the reference relies on. */
 typedef struct vsf_params {
   /* FeatureDetectorShiTomasiBucketing ctor (FeatureDetectorShiTomasiBucketing.hpp:32-35) */
-  int32_t grid_rows;      /* division_number_row */
+  int32_t grid_rows;      /* division_number_row (rows x cols <= 65535 cells) */
   int32_t grid_cols;      /* division_number_col */
   int32_t max_features;   /* max_feature_number  */
   double min_distance;    /* min_feature_distance */
@@ -57,7 +57,7 @@ typedef struct vsf_params {
   double min_eig_thr;     /* 1e-4, cv::calcOpticalFlowPyrLK default */
   double backtrack_thr;   /* backtrack_distance_threshold */
   /* geometry and sizing of this context */
-  int32_t width, height;  /* frame size (8-bit, single channel) */
+  int32_t width, height;  /* frame size (8-bit, single channel); each <= 65535 (ANMS detector: <= 32767) */
   int32_t streams;        /* independent streams held by this context (>= 1) */
   int32_t capacity;       /* feature-table capacity per stream; 0 = max_features + 64 */
   int32_t device_id;      /* HIP device ordinal */
