@@ -12,9 +12,11 @@ def rank_main(rank):
     from _pkg import load_package, load_synth
     vsf, synth = load_package(), load_synth()
     w, h, B = 160, 120, 3
+    dev = rank if torch.cuda.device_count() >= 2 else 0   # two GPUs visible: the real thing
+    torch.cuda.set_device(dev)
     frames = np.stack([synth.sequence(300 + 10 * rank + s, w, h, 2)[0] for s in range(B)], 1)
     ctx = vsf.Context(vsf.default_params(width=w, height=h, streams=B, max_features=40, grid_rows=2, grid_cols=2,
-                                         min_distance=4.0, klt_win=9, klt_max_level=1))
+                                         min_distance=4.0, klt_win=9, klt_max_level=1, device_id=dev))
     d = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
     for t in range(2):
         ctx.batch_step(d[t].data_ptr(), w * h, w, 0)
@@ -32,7 +34,7 @@ def rank_main(rank):
             time.sleep(0.05)
     ident = open(idf, "rb").read()
     print("rank", rank, "creating communicator", flush=True)
-    comm = vsf.Comm(ident, rank, 2, 0)
+    comm = vsf.Comm(ident, rank, 2, dev)
     print("rank", rank, "communicator up", flush=True)
     recv = torch.zeros(2 * B * ctx.capacity * 24, dtype=torch.uint8, device="cuda")
     ctx.gather_tracks(comm, recv.data_ptr(), 0)
