@@ -375,7 +375,12 @@ int orc_calc_optical_flow_pyr_lk(const uint8_t* prev, int prev_stride, const uin
  * Box filter: OpenCV's boxFilter accumulates 32F input in 64F (createBoxFilter: sumType=CV_64F),
  * so the block sum is formed in double -- row sums left to right, then the column of row sums top
  * to bottom -- and rounded to float32 once.  (SURVEY A.1 step 3 words this with float sums; the
- * double form is what OpenCV does and makes the result independent of its running-sum order.)
+ * double form is what OpenCV does.  OpenCV's ColumnSum -- and its RowSum for block sizes other than 3 and 5 -- is a
+ * RUNNING sum: add the entering element, subtract the leaving one.  The two forms give the same double unless an
+ * addition is inexact, which needs summands some 29 bits apart in magnitude: a Dy that should be 0 and is a
+ * rounding residue of ~7e-9 beside gradients of 0.1.  That moves the double by its last bit and the float32 result
+ * about once in 1e11 pixels; restating the running form would tie every pixel to the whole column above it.  Part of
+ * what "PARITY UNPINNED" in the header covers.)
  * The box filter reflects (REFLECT_101) at the borders of the ROI's own covariance image. */
 static void corner_response(const uint8_t* img, int img_w, int img_h, int stride, int rx, int ry, int rw, int rh,
                             int block_size, int use_harris, double harris_k, float* eig) {
