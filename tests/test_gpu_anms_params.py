@@ -177,3 +177,45 @@ def test_anms_batch_with_min_distance_and_harris(vsf, oracle, synth, B):
             assert np.array_equal(xy[s, :m], tabs[s % U].xy[:m])
     assert (ctx.batch_status() == 0).all()
     ctx.close()
+
+
+def test_anms_params_with_user_mask_and_bgr_input(vsf, oracle, synth):
+    """Harris + minimum distance together, behind a user mask, on a 3-channel frame (converted on the device)."""
+    w, h = 320, 240
+    frames, _ = synth.sequence(61, w, h, 3)
+    mask = np.full((h, w), 255, np.uint8)
+    mask[:, 200:] = 0
+    mask[60:90, :] = 2     # even: wiped by the AND with the edge mask of ones
+    gpu_kw = dict(anms_use_harris=1, anms_harris_k=0.05, anms_detection_min_distance=3.3)
+    orc_kw = dict(detection_use_harris_corner=1, detection_k=0.05, detection_min_feature_distance=3.3)
+    _run_sequence(vsf, oracle, frames, w, h, 120, 8.0, gpu_kw, orc_kw, dict(use_harris=True, k=0.05), mask=mask)
+    # the same frame as BGR (B = G = R: the fixed-point gray weights sum to 2^14, the conversion is the identity)
+    ctx = vsf.Context(vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, max_features=120, min_distance=8.0,
+                                         width=w, height=h, **gpu_kw))
+    ids, xy, age = _table(ctx.capacity)
+    bgr = np.repeat(frames[0][:, :, None], 3, axis=2)
+    n = ctx.detect(bgr, ids, xy, age, 0, mask)
+    det, T = oracle.AnmsDetector(120, 8.0, **orc_kw), oracle.FeatureTable(ctx.capacity)
+    det.update_detection(T, frames[0], mask)
+    assert n == T.n.value > 30 and np.array_equal(xy[:n], T.xy[:n]) and (xy[:n, 0] < 200).all()
+    ctx.close()
+
+
+def test_anms_min_distance_up_to_one_changes_nothing_and_limits_are_refused(vsf, synth):
+    import ctypes as C
+    w, h = 200, 150
+    fr = synth.sequence(62, w, h, 1)[0][0]
+    outs = []
+    for md in (1.0, 0.0, 0.5, -3.0):     # cv: minDistance < 1 runs no distance test, 1 never fails it
+        ctx = vsf.Context(vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, max_features=60, min_distance=6.0,
+                                             width=w, height=h, anms_detection_min_distance=md))
+        ids, xy, age = _table(ctx.capacity)
+        n = ctx.detect(fr, ids, xy, age, 0)
+        outs.append((n, xy[:n].copy()))
+        ctx.close()
+    assert all(o[0] == outs[0][0] > 20 and np.array_equal(o[1], outs[0][1]) for o in outs[1:])
+    hnd = C.c_void_p()
+    for kw in (dict(anms_detection_min_distance=31.5), dict(anms_detection_min_distance=float("nan")),
+               dict(anms_use_harris=1, anms_harris_k=float("inf"))):
+        p = vsf.default_params(detector_kind=vsf.DETECTOR_ANMS, max_features=60, min_distance=6.0, width=w, height=h, **kw)
+        assert vsf.lib().vsf_create(C.byref(p), C.byref(hnd)) == vsf.VSF_E_INVALID, kw
