@@ -325,6 +325,10 @@ int vsf_lk_points_noalloc(const vsf_params* p, const uint8_t* d_prev, int32_t pr
 #define VSF_K_SELECT 6
 #define VSF_K_APPEND 7
 #define VSF_K_COUNT 8
+/* on: 0 = off, 1 = every kernel class above, otherwise a mask with bit (1 + VSF_K_x) set for the classes to time
+ * (e.g. 1 << (1 + VSF_K_LK): the tracker only).  An event pair around a kernel drains the stream before and after
+ * it -- about 8 us of idle GPU each; sixteen of them cost the C2 step 3-5 % --, so a caller that times a whole
+ * run asks for the one class it needs and takes the full breakdown from a few extra steps. */
 int vsf_profile_enable(vsf_ctx* ctx, int32_t on);
 /* Diagnostic: the shader clock the GPU holds right now.  A one-lane kernel on a stream of its own spins for spin_us
  * microseconds of the constant-rate counter (s_memrealtime) and reports the advance of the shader cycle counter

@@ -412,8 +412,10 @@ class Context:
         self._chk(lib().vsf_debug_sclk_probe(self._h, int(spin_us), C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def profile_enable(self, on=True):
-        self._chk(lib().vsf_profile_enable(self._h, 1 if on else 0))
+    def profile_enable(self, on=True, kernels=None):
+        """kernels: indices of the kernel classes to time (K_* below); None = all of them."""
+        v = 0 if not on else (1 if kernels is None else sum(1 << (1 + k) for k in kernels))
+        self._chk(lib().vsf_profile_enable(self._h, v))
 
     def profile_read(self):
         ms = (C.c_float * len(KERNEL_NAMES))()

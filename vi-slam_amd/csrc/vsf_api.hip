@@ -123,7 +123,7 @@ struct vsf_ctx {
   LkParams lk;
   LkSmem lks;
   // profiling
-  bool prof = false;
+  unsigned int prof = 0;  // bit k: kernel class k is timed (vsf_profile_enable)
   std::vector<EvPair> ev_used;
   std::vector<EvPair> ev_free;
   char err[256] = {0};
@@ -213,7 +213,7 @@ struct ProfScope {
   hipStream_t s;
   EvPair e;
   bool on;
-  ProfScope(vsf_ctx* c_, int kid, hipStream_t s_) : c(c_), s(s_), on(c_->prof) {
+  ProfScope(vsf_ctx* c_, int kid, hipStream_t s_) : c(c_), s(s_), on((c_->prof >> kid) & 1u) {
     if (!on) return;
     if (!c->ev_free.empty()) {
       e = c->ev_free.back();
@@ -1934,7 +1934,7 @@ int vsf_debug_sclk_probe(vsf_ctx* c, int32_t spin_us, double* sclk_mhz, double* 
 
 int vsf_profile_enable(vsf_ctx* c, int32_t on) {
   if (!c) return VSF_E_INVALID;
-  c->prof = on != 0;
+  c->prof = on == 0 ? 0u : (on == 1 ? (1u << VSF_K_COUNT) - 1u : ((unsigned int)on >> 1) & ((1u << VSF_K_COUNT) - 1u));
   return VSF_OK;
 }
 
