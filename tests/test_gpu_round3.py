@@ -198,3 +198,28 @@ def test_sclk_probe(vsf):
     ctx = vsf.Context(vsf.default_params(width=320, height=240))
     mhz, rt = ctx.sclk_probe(3000)
     assert 10.0 < rt < 1000.0 and 50.0 < mhz < 4000.0
+
+
+def test_profile_class_mask(vsf, synth):
+    """vsf_profile_enable with a class mask: only the asked kernel classes sit between events."""
+    import torch
+    w, h, B = 160, 120, 2
+    frames = np.stack([synth.sequence(90 + s, w, h, 4)[0] for s in range(B)], 1)
+    d = torch.from_numpy(np.ascontiguousarray(frames)).cuda()
+    ctx = vsf.Context(vsf.default_params(width=w, height=h, streams=B, max_features=40, grid_rows=2, grid_cols=2,
+                                         min_distance=4.0, klt_win=9, klt_max_level=1))
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.batch_step(d[0].data_ptr(), h * w, w, s)
+    lk = vsf.KERNEL_NAMES.index("lk")
+    ctx.profile_enable(True, kernels=[lk])
+    ctx.batch_step(d[1].data_ptr(), h * w, w, s)
+    ctx.batch_step(d[2].data_ptr(), h * w, w, s)
+    ctx.profile_enable(False)
+    prof = ctx.profile_read()
+    assert prof["lk"][1] == 2 and prof["lk"][0] > 0 and all(v[1] == 0 for k, v in prof.items() if k != "lk")
+    ctx.profile_enable(True)
+    ctx.batch_step(d[3].data_ptr(), h * w, w, s)
+    ctx.profile_enable(False)
+    prof = ctx.profile_read()
+    assert prof["lk"][1] == 1 and prof["score"][1] >= 1 and prof["pyramid"][1] >= 1
+    ctx.close()
