@@ -7,6 +7,7 @@
 // None of those libraries is present here: PARITY UNPINNED beyond the format specifications themselves
 // (PNG / zlib / JSON are standards; the decoder is checked against an independent PNG implementation in
 // tests/test_euroc_ingest.py).
+#include <sys/stat.h>
 #include "../../include/vsf_io.h"
 
 #include <zlib.h>
@@ -33,13 +34,14 @@ int fail(int code, const std::string& msg) {
 bool read_file(const std::string& path, std::vector<uint8_t>& out) {
   FILE* f = std::fopen(path.c_str(), "rb");
   if (!f) return false;
-  std::fseek(f, 0, SEEK_END);
-  const long n = std::ftell(f);
-  std::fseek(f, 0, SEEK_SET);
-  if (n < 0) {
+  // a regular file of a sane size only: fopen opens a DIRECTORY too (an empty file name in data.csv names the
+  // data directory itself), whose "size" by ftell is LONG_MAX -- an allocation that throws through the C ABI
+  struct stat st;
+  if (fstat(fileno(f), &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 0 || st.st_size > (off_t)1 << 31) {
     std::fclose(f);
     return false;
   }
+  const long n = (long)st.st_size;
   out.resize((size_t)n);
   const size_t got = n ? std::fread(out.data(), 1, (size_t)n, f) : 0;
   std::fclose(f);
