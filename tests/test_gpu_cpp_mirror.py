@@ -80,3 +80,17 @@ def test_cpp_mirror_lssd_tracker_matches_oracle(oracle, synth, tmp_path, det_arg
         assert got[k]["tab"] == tab.as_dict(), "frame %d" % k
         assert got[k]["maxidx"] == det.max_feature_index
     assert len(got[-1]["tab"]) > 20
+
+
+@pytest.mark.gpu
+def test_abi_walk_from_cpp(synth, tmp_path):
+    """tests/cpp/abi_exercise_main.cpp: every kind of C ABI entry from a C++ host, refused parameters and error
+    paths included; it checks return codes and invariants (results are the other tests' business)."""
+    exe = os.path.join(ROOT, "tests", "cpp", "abi_exercise_main")
+    assert os.path.exists(exe), "run __graft_entry__.build()"
+    w, h, n = 400, 300, 5
+    frames, _ = synth.sequence(79, w, h, n)
+    raw = str(tmp_path / "f.raw")
+    frames.tofile(raw)
+    p = subprocess.run([exe, raw, str(w), str(h), str(n)], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "abi exercise ok" in p.stdout, p.stdout[-1000:] + p.stderr[-2000:]
