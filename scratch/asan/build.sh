@@ -4,10 +4,10 @@
 set -eu
 cd "$(dirname "$0")"
 CL=/opt/rocm/lib/llvm/bin/clang++
-/opt/rocm/bin/hipcc -O1 -g --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -Xarch_host -fsanitize=address \
+/opt/rocm/bin/hipcc -O1 -g --offload-arch=gfx950 -ffp-contract=off -fPIC -shared -std=c++17 -Xarch_host -fsanitize=address -Xarch_host -fsanitize=undefined \
   -o libvsf_hip.so ../../vi-slam_amd/csrc/vsf_api.hip
-$CL -std=c++17 -O1 -g -fsanitize=address -I ../../include -I ../../vi-slam_amd/host ../../tests/cpp/frontend_mirror_main.cpp \
+$CL -std=c++17 -O1 -g -fsanitize=address,undefined -I ../../include -I ../../vi-slam_amd/host ../../tests/cpp/frontend_mirror_main.cpp \
   -o frontend_mirror_asan -L . -lvsf_hip -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib
-$CL -std=c++17 -O1 -g -fsanitize=address -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include -I ../../include \
+$CL -std=c++17 -O1 -g -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include -I ../../include \
   ../../tests/cpp/abi_exercise_main.cpp -o abi_exercise_asan -L . -lvsf_hip -L /opt/rocm/lib -lamdhip64 \
   -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib

@@ -11,6 +11,7 @@ fr, _ = synth.sequence(77, 400, 300, 5)
 fr.tofile('gpurun_out/asan_frames.raw')
 PY
 export ASAN_OPTIONS=detect_leaks=0:protect_shadow_gap=0:abort_on_error=0
+export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 for args in "3 3 180 5.0 30 0.01 21 3 1.0" "0 0 120 9.0 30 0.01 21 3 1.0" "0 1 120 9.0 30 0.01 21 3 1.0" "3 3 180 5.0 0 0 0 0 0" "0 0 120 9.0 0 0 0 0 0"; do
   timeout -k 10 120 scratch/asan/frontend_mirror_asan gpurun_out/asan_frames.raw 400 300 5 gpurun_out/asan_out.txt $args > gpurun_out/asan_run.log 2>&1
   rc=$?
