@@ -956,7 +956,11 @@ int orc_ssc(const float* kxy, int n, int num_ret, float tolerance, int cols, int
   const double exp4 = num_ret - 1;
   const double sol1 = -round((exp1 + exp3) / exp4); /* :359-360 */
   const double sol2 = -round((exp1 - exp3) / exp4);
-  int high = (int)((sol1 > sol2) ? sol1 : sol2);   /* :362-365 */
+  /* :362-365 `int high = sol1 > sol2 ? sol1 : sol2`.  With num_ret == 1 exp4 is 0 and the larger solution +inf: the
+   * conversion is undefined in C++; the reference's x86-64 binary (cvttsd2si) gets INT_MIN for anything outside int,
+   * which is what is restated here without the undefined behaviour. */
+  const double hsol = (sol1 > sol2) ? sol1 : sol2;
+  int high = (hsol >= -2147483648.0 && hsol < 2147483648.0) ? (int)hsol : (-2147483647 - 1);
   int low = (int)floor(sqrt((double)n / num_ret)); /* :366 */
   int width, prev_width = -1;
   const unsigned int K = (unsigned int)num_ret;
@@ -966,7 +970,11 @@ int orc_ssc(const float* kxy, int n, int num_ret, float tolerance, int cols, int
   int nres = 0, nfinal = 0;
   int* res = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
   for (;;) {
-    width = low + (high - low) / 2; /* :380 */
+    /* :380 `low + (high - low) / 2`; with high = INT_MIN (above) the subtraction overflows: undefined in C++, a
+     * wrapping subtract in the reference's binary -- restated with unsigned arithmetic.  The width is then about
+     * 2^30, every keypoint falls into cell (0, 0), the first one is the result: what the HIP kernel returns too
+     * (its conversion saturates to INT_MAX, a width within 1 of this one). */
+    width = (int)((unsigned int)low + (unsigned int)((int)((unsigned int)high - (unsigned int)low) / 2));
     if (width == prev_width || low > high) { /* :381-386 previous iteration's result */
       nfinal = nres;
       memcpy(result, res, sizeof(int) * (size_t)nres);
