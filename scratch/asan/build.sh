@@ -11,3 +11,6 @@ $CL -std=c++17 -O1 -g -fsanitize=address,undefined -I ../../include -I ../../vi-
 $CL -std=c++17 -O1 -g -fsanitize=address,undefined -D__HIP_PLATFORM_AMD__ -I /opt/rocm/include -I ../../include \
   ../../tests/cpp/abi_exercise_main.cpp -o abi_exercise_asan -L . -lvsf_hip -L /opt/rocm/lib -lamdhip64 \
   -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+$CL -std=c++17 -O1 -g -fPIC -shared -fsanitize=address,undefined -o libvsf_io.so ../../vi-slam_amd/csrc/vsf_io.cpp -lz
+$CL -std=c++17 -O1 -g -fsanitize=address,undefined -I ../../include -I ../../vi-slam_amd/host ../../tests/cpp/euroc_example_main.cpp \
+  -o euroc_example_asan -L . -lvsf_hip -lvsf_io -Wl,-rpath,'$ORIGIN' -Wl,-rpath,/opt/rocm/lib -Wl,-rpath-link,/opt/rocm/lib

@@ -22,3 +22,18 @@ timeout -k 10 120 scratch/asan/abi_exercise_asan gpurun_out/asan_frames.raw 400 
 rc=$?
 echo "abi exercise rc $rc"; tail -5 gpurun_out/asan_abi.log | cut -c1-250
 [ $rc -eq 0 ] || { head -60 gpurun_out/asan_abi.log | cut -c1-250; exit 1; }
+python3 - <<'PY'
+import sys
+sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
+from _pkg import load_synth
+from test_euroc_ingest import make_dataset
+import shutil, os
+root = 'gpurun_out/asan_euroc/V1_01_easy'
+shutil.rmtree('gpurun_out/asan_euroc', ignore_errors=True)
+fr, _ = load_synth().sequence(81, 376, 240, 12)
+make_dataset(root, fr)
+PY
+timeout -k 10 120 scratch/asan/euroc_example_asan gpurun_out/asan_euroc/V1_01_easy gpurun_out/asan_euroc/V1_01_easy/calib.json gpurun_out/asan_euroc_out.txt > gpurun_out/asan_euroc.log 2>&1
+rc=$?
+echo "euroc example rc $rc lines $(wc -l < gpurun_out/asan_euroc_out.txt)"
+[ $rc -eq 0 ] || { head -60 gpurun_out/asan_euroc.log | cut -c1-250; exit 1; }
